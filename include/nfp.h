@@ -1,0 +1,119 @@
+/*
+ * nfp.h — C ABI of libnfp_hip.so, the MI355X (gfx950) Neighbourhood Feature
+ * Pooling forward/backward.
+ *
+ * The reference has no FFI layer: its operator API is the Python class
+ * models/pooling/nfp.py::NFPPooling (nfp.py:15-134).  This header is the
+ * boundary a binding for that class calls; every entry point names the
+ * reference code it stands in for.  Plain pointers and sizes only — no torch
+ * types.  All tensor pointers are DEVICE pointers; the caller owns every
+ * buffer (the library never allocates, frees or retains one), kernels are
+ * enqueued on the caller's hipStream_t and nothing synchronises the device.
+ *
+ * Return value of every int function: 0 = ok, <0 = NFP_E_* below (message in
+ * nfp_last_error(), thread-local).  Nothing throws or aborts.
+ */
+#ifndef NFP_H_
+#define NFP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NFP_ABI_VERSION 1
+
+/* error codes */
+#define NFP_OK 0
+#define NFP_E_INVALID (-1)     /* malformed descriptor / null pointer          */
+#define NFP_E_UNSUPPORTED (-2) /* valid for the reference, not built here yet  */
+#define NFP_E_HIP (-3)         /* a HIP runtime call failed                    */
+
+/* nfp.py:85-120 — the `measure` string, lower-cased, dispatches to one of
+ * these (same order as the if/elif chain there; 'scs' aliases 16). */
+enum nfp_measure {
+  NFP_NORM = 0,         /* nfp.py:141-148  LA.norm(centre-neigh, ord=p, dim=C)      */
+  NFP_COSINE = 1,       /* nfp.py:150-159  F.cosine_similarity(centre, neigh, eps)  */
+  NFP_DOT = 2,          /* nfp.py:161-170                                           */
+  NFP_RMSE = 3,         /* nfp.py:172-179                                           */
+  NFP_GEMAN = 4,        /* nfp.py:181-193                                           */
+  NFP_ATTENTION = 5,    /* nfp.py:195-205  softmax over the N neighbours            */
+  NFP_EMD = 6,          /* nfp.py:207-216                                           */
+  NFP_CANBERRA = 7,     /* nfp.py:218-227                                           */
+  NFP_HELLINGER = 8,    /* nfp.py:229-241                                           */
+  NFP_CHISQUARED1 = 9,  /* nfp.py:243-252                                           */
+  NFP_CHISQUARED2 = 10, /* nfp.py:254-263                                           */
+  NFP_GFC = 11,         /* nfp.py:265-276                                           */
+  NFP_PEARSON = 12,     /* nfp.py:278-293                                           */
+  NFP_JEFFREY = 13,     /* nfp.py:295-308                                           */
+  NFP_SQUAREDCHORD = 14,/* nfp.py:310-324                                           */
+  NFP_SMITH = 15,       /* nfp.py:326-342                                           */
+  NFP_SCS = 16,         /* nfp.py:344-374  (batch-mixing broadcast)  */
+  NFP_MEASURE_COUNT = 17
+};
+
+/* nn.Conv2d padding_mode of the two frozen depthwise convs (nfp.py:42-58). */
+enum nfp_pad_mode { NFP_PAD_ZEROS = 0, NFP_PAD_REFLECT = 1, NFP_PAD_REPLICATE = 2, NFP_PAD_CIRCULAR = 3 };
+
+enum nfp_dtype { NFP_F32 = 0, NFP_BF16 = 1 }; /* storage type of x / out / grads; arithmetic is f32 */
+
+/*
+ * One NFP call.  Mirrors NFPPooling.__init__ (nfp.py:16-39) plus the input
+ * geometry forward() sees (nfp.py:132-134).  Strides are in ELEMENTS, so NCHW
+ * and channels-last inputs are both read in place (no transpose kernel).
+ */
+typedef struct nfp_desc {
+  int32_t B, C, H, W;        /* input  [B,C,H,W]                                        */
+  int32_t R;                 /* radius; kernel_size k = 2R+1, N = k*k-1   nfp.py:38-39  */
+  int32_t pad, stride, dilation; /* conv geometry                         nfp.py:42-47  */
+  int32_t pad_mode;          /* enum nfp_pad_mode                                       */
+  int32_t measure;           /* enum nfp_measure                                        */
+  int32_t similarity;        /* nfp.py:29 — sign / (1-x) convention of each measure     */
+  int32_t diff_weights;      /* 1 when the RAW measure string was in
+                                ['norm','rmse','mahalanobis'] (nfp.py:74-76): the conv
+                                yields centre-neighbour; 0: pure neighbour (nfp.py:79-80) */
+  int32_t dtype;             /* enum nfp_dtype                                          */
+  float p;                   /* nfp.py:30 — ord of Norm, exponent of SCS                */
+  float eps;                 /* nfp.py:33                                               */
+  float q_scs;               /* nfp.py:34                                               */
+  int64_t sxB, sxC, sxH, sxW; /* element strides of x (and of grad_x)                   */
+} nfp_desc;
+
+int nfp_abi_version(void);
+const char* nfp_last_error(void);
+
+/* out is [B, N, Ho, Wo] contiguous; Ho/Wo as nn.Conv2d computes them
+ * (nfp.py:125-130 is the square-only helper of the same formula). */
+int nfp_output_shape(const nfp_desc* d, int32_t* N, int32_t* Ho, int32_t* Wo);
+
+/* Floats of per-call state forward() hands to backward() (the autograd
+ * "saved tensors" that replace the [B,C,N,H,W] graph of nfp.py:152-156).
+ * 0 when the measure needs none. */
+int64_t nfp_saved_floats(const nfp_desc* d);
+
+/* NFPPooling.forward (nfp.py:132-134) for the measure in d.
+ *   x      [B,C,H,W] by strides, dtype d->dtype
+ *   out    [B,N,Ho,Wo] contiguous, dtype d->dtype
+ *   saved  float[nfp_saved_floats(d)] or NULL when no backward will follow */
+int nfp_forward(const nfp_desc* d, const void* x, void* out, float* saved, void* hip_stream);
+
+/* The autograd backward of the same call: grad_x = d(sum(out*grad_out))/dx.
+ *   grad_out [B,N,Ho,Wo] contiguous;  out / saved as written by nfp_forward
+ *   grad_x   [B,C,H,W] with the strides of x; fully overwritten */
+int nfp_backward(const nfp_desc* d, const void* x, const void* grad_out, const void* out,
+                 const float* saved, void* grad_x, void* hip_stream);
+
+/* Telemetry: kernels enqueued by this process so far (tests use it to prove
+ * the HIP path, not a fallback, produced a result). */
+uint64_t nfp_launch_count(void);
+
+/* Name of the kernel variant the last nfp_forward / nfp_backward on this
+ * thread selected (for bench / profile bookkeeping). */
+const char* nfp_last_variant(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NFP_H_ */

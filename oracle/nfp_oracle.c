@@ -1,0 +1,555 @@
+/*
+ * nfp_oracle.c — TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * A scalar CPU restatement (plain C, double accumulation) of the reference's
+ * Neighbourhood Feature Pooling forward and of its autograd backward, used
+ * only as the checker by tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg.  Nothing under neighbour_feature_pooling_amd/ imports,
+ * links or calls it.
+ *
+ * Parity pin: tests/test_oracle_golden.py checks every function here against
+ * the .npz fixtures in tests/golden/, which tests/golden/make_golden.py produced by importing
+ * the real reference (/root/reference/models/pooling/nfp.py, torch 2.10 CPU).
+ *
+ * What is restated (reference file:line):
+ *   geometry    the two frozen one-hot depthwise convs, nn.Conv2d(k=2R+1, stride,
+ *               padding, padding_mode, dilation, groups=C)     nfp.py:42-82
+ *   neighbour order  row-major (ky,kx) with the centre skipped  nfp.py:64-68
+ *   channel packing  c*N+n -> [B,C,N,H,W]                       nfp.py:136-139
+ *   measures    Norm 141-148, Cosine 150-159, DotProduct 161-170, RMSE 172-179,
+ *               GMC 181-193, Attention 195-205, EMD 207-216, Canberra 218-227,
+ *               Hellinger 229-241, ChiSquared1 243-252, ChiSquared2 254-263,
+ *               GFC 265-276, Pearson 278-293, Jeffrey 295-308,
+ *               SquaredChord 310-324, Smith 326-342, SharpenedCosine 344-374
+ *   third-party arithmetic (not under /root/reference; torch 2.10.0 as installed):
+ *               F.cosine_similarity = sum( x1/m1 * x2/m2 ), m = clamp_min_(|x|.clone(), eps) done in
+ *               place under NoGradGuard, so backward still differentiates through |x| (clamped VALUE,
+ *               un-gated gradient);
+ *               linalg.vector_norm backward is 0 where the norm is 0;
+ *               abs backward = sign (0 at 0); minimum backward splits ties 1/2.
+ */
+#include "../include/nfp.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ---- geometry ------------------------------------------------------------------ */
+
+/* index into the un-padded axis of length n for padded coordinate t = i - pad, or -1
+ * for a zero-padded tap.  nn.Conv2d padding_mode -> F.pad(mode) semantics. */
+static int map_index(int t, int n, int mode) {
+  if (t >= 0 && t < n) return t;
+  switch (mode) {
+    case NFP_PAD_ZEROS: return -1;
+    case NFP_PAD_REFLECT: return t < 0 ? -t : 2 * (n - 1) - t;
+    case NFP_PAD_REPLICATE: return t < 0 ? 0 : n - 1;
+    case NFP_PAD_CIRCULAR: return ((t % n) + n) % n;
+  }
+  return -1;
+}
+
+static int out_extent(int n, int pad, int dil, int k, int stride) {
+  return (n + 2 * pad - dil * (k - 1) - 1) / stride + 1;
+}
+
+int nfp_oracle_output_shape(const nfp_desc* d, int* N, int* Ho, int* Wo) {
+  int k = 2 * d->R + 1;
+  if (d->R < 1 || d->stride < 1 || d->dilation < 1 || d->pad < 0) return NFP_E_INVALID;
+  if (d->H + 2 * d->pad < d->dilation * (k - 1) + 1 || d->W + 2 * d->pad < d->dilation * (k - 1) + 1)
+    return NFP_E_INVALID;
+  if (d->pad_mode == NFP_PAD_REFLECT && (d->pad >= d->H || d->pad >= d->W)) return NFP_E_INVALID;
+  if (d->pad_mode == NFP_PAD_CIRCULAR && (d->pad > d->H || d->pad > d->W)) return NFP_E_INVALID;
+  *N = k * k - 1;
+  *Ho = out_extent(d->H, d->pad, d->dilation, k, d->stride);
+  *Wo = out_extent(d->W, d->pad, d->dilation, k, d->stride);
+  return NFP_OK;
+}
+
+/* flat input pixel (y*W+x) of tap (ky,kx) of output (oy,ox); -1 = zero padding */
+static int tap_pixel(const nfp_desc* d, int oy, int ox, int ky, int kx) {
+  int y = map_index(oy * d->stride + ky * d->dilation - d->pad, d->H, d->pad_mode);
+  int x = map_index(ox * d->stride + kx * d->dilation - d->pad, d->W, d->pad_mode);
+  if (y < 0 || x < 0) return -1;
+  return y * d->W + x;
+}
+
+static void gather(const nfp_desc* d, const float* x, int b, int pix, double* v) {
+  int C = d->C;
+  if (pix < 0) {
+    for (int c = 0; c < C; ++c) v[c] = 0.0;
+    return;
+  }
+  int y = pix / d->W, xx = pix % d->W;
+  const float* base = x + (int64_t)b * d->sxB + (int64_t)y * d->sxH + (int64_t)xx * d->sxW;
+  for (int c = 0; c < C; ++c) v[c] = (double)base[(int64_t)c * d->sxC];
+}
+
+static void scatter_add(const nfp_desc* d, double* gx, int b, int pix, const double* g, double scale) {
+  if (pix < 0) return;
+  int C = d->C;
+  double* base = gx + ((int64_t)b * C) * d->H * d->W + pix; /* gx is dense [B,C,H*W] doubles */
+  int64_t HW = (int64_t)d->H * d->W;
+  for (int c = 0; c < C; ++c) base[c * HW] += scale * g[c];
+}
+
+/* ---- pairwise measures: f(a = centre, b = neighbour) and its two gradients -------- */
+
+static double sgn(double v) { return (v > 0) - (v < 0); }
+
+typedef struct {
+  int C, measure, similarity, diff;
+  double p, eps;
+} pm;
+
+/* returns the output value; when da/db are non-NULL also d f/d a and d f/d b.
+ * Attention returns the raw dot (softmax over n applied by the caller); SCS is
+ * handled by the caller entirely. */
+static double pair_eval(const pm* m, const double* a, const double* b, double* da, double* db) {
+  const int C = m->C;
+  const double eps = m->eps;
+  double f = 0.0;
+  int c;
+  const int want = da != NULL;
+  switch (m->measure) {
+    case NFP_NORM:
+    case NFP_RMSE: {
+      /* v = conv output: centre-neighbour (nfp.py:75-76) or pure neighbour (nfp.py:79-80) */
+      double s = 0.0, dn;
+      double p = m->p;
+      if (m->measure == NFP_RMSE) p = 2.0;
+      for (c = 0; c < C; ++c) {
+        double v = m->diff ? a[c] - b[c] : b[c];
+        s += (p == 2.0) ? v * v : (p == 1.0 ? fabs(v) : pow(fabs(v), p));
+      }
+      if (m->measure == NFP_RMSE) {
+        dn = sqrt(s / C); /* nfp.py:176 */
+      } else {
+        dn = (p == 2.0) ? sqrt(s) : (p == 1.0 ? s : pow(s, 1.0 / p)); /* nfp.py:145 */
+      }
+      f = m->similarity ? -dn : dn;
+      if (want) {
+        double sg = m->similarity ? -1.0 : 1.0;
+        for (c = 0; c < C; ++c) {
+          double v = m->diff ? a[c] - b[c] : b[c];
+          double g;
+          if (m->measure == NFP_RMSE) {
+            g = (0.5 / dn) * (2.0 * v / C); /* sqrt'(mean) * mean' : NaN when dn == 0, as torch */
+          } else if (p == 2.0) {
+            g = dn == 0.0 ? 0.0 : v / dn;
+          } else if (p == 1.0) {
+            g = sgn(v);
+          } else {
+            g = dn == 0.0 ? 0.0 : sgn(v) * pow(fabs(v), p - 1.0) / pow(dn, p - 1.0);
+          }
+          g *= sg;
+          if (m->diff) {
+            da[c] = g;
+            db[c] = -g;
+          } else {
+            da[c] = 0.0;
+            db[c] = g;
+          }
+        }
+      }
+      return f;
+    }
+    case NFP_COSINE: {
+      double na = 0, nb = 0, dot = 0;
+      for (c = 0; c < C; ++c) {
+        na += a[c] * a[c];
+        nb += b[c] * b[c];
+      }
+      na = sqrt(na);
+      nb = sqrt(nb);
+      double ma = na > eps ? na : eps, mb = nb > eps ? nb : eps;
+      for (c = 0; c < C; ++c) dot += (a[c] / ma) * (b[c] / mb);
+      f = m->similarity ? dot : 1.0 - dot; /* nfp.py:157-158 */
+      if (want) {
+        double sg = m->similarity ? 1.0 : -1.0;
+        /* torch clamps the norms in place under NoGradGuard: the graph still sees d|a|/da = a/|a|
+         * (0 where |a| == 0) while the VALUES used are the clamped ones. */
+        double ka = na > 0 ? 1.0 : 0.0, kb = nb > 0 ? 1.0 : 0.0;
+        for (c = 0; c < C; ++c) {
+          double ah = a[c] / ma, bh = b[c] / mb;
+          da[c] = sg * (bh / ma - ka * dot * (na > 0 ? a[c] / na : 0.0) / ma);
+          db[c] = sg * (ah / mb - kb * dot * (nb > 0 ? b[c] / nb : 0.0) / mb);
+        }
+      }
+      return f;
+    }
+    case NFP_DOT:
+    case NFP_ATTENTION: {
+      for (c = 0; c < C; ++c) f += a[c] * b[c];
+      double sg = (m->measure == NFP_DOT && !m->similarity) ? -1.0 : 1.0; /* nfp.py:168-169 */
+      if (want)
+        for (c = 0; c < C; ++c) {
+          da[c] = sg * b[c];
+          db[c] = sg * a[c];
+        }
+      return sg * f;
+    }
+    case NFP_GEMAN: {
+      for (c = 0; c < C; ++c) {
+        double q = (a[c] - b[c]) * (a[c] - b[c]);
+        f += q / (q + eps);
+      }
+      f /= C;
+      if (want) {
+        double sg = m->similarity ? 1.0 : -1.0;
+        for (c = 0; c < C; ++c) {
+          double v = a[c] - b[c], q = v * v;
+          double g = sg * 2.0 * v * eps / ((q + eps) * (q + eps)) / C;
+          da[c] = g;
+          db[c] = -g;
+        }
+      }
+      return m->similarity ? f : 1.0 - f; /* nfp.py:191-192 */
+    }
+    case NFP_EMD: {
+      for (c = 0; c < C; ++c) f += fabs(a[c] - b[c]);
+      double sg = m->similarity ? -1.0 : 1.0;
+      if (want)
+        for (c = 0; c < C; ++c) {
+          da[c] = sg * sgn(a[c] - b[c]);
+          db[c] = -da[c];
+        }
+      return sg * f;
+    }
+    case NFP_CANBERRA: {
+      double sg = m->similarity ? -1.0 : 1.0;
+      for (c = 0; c < C; ++c) {
+        double u = fabs(a[c] - b[c]), w = fabs(a[c]) + fabs(b[c]) + eps;
+        f += u / w;
+        if (want) {
+          double s = sgn(a[c] - b[c]);
+          da[c] = sg * (s / w - u * sgn(a[c]) / (w * w));
+          db[c] = sg * (-s / w - u * sgn(b[c]) / (w * w));
+        }
+      }
+      return sg * f;
+    }
+    case NFP_HELLINGER:
+    case NFP_SQUAREDCHORD: {
+      double S = 0;
+      for (c = 0; c < C; ++c) {
+        double ra = sqrt(fabs(a[c]) + eps), rb = sqrt(fabs(b[c]) + eps);
+        S += (ra - rb) * (ra - rb);
+      }
+      double sg = m->similarity ? -1.0 : 1.0;
+      double outer; /* d f / d S */
+      if (m->measure == NFP_HELLINGER) {
+        f = sqrt(0.5 * S);
+        outer = 0.25 / f; /* inf at S == 0 -> 0*inf = NaN, as torch */
+      } else {
+        f = S;
+        outer = 1.0;
+      }
+      if (want)
+        for (c = 0; c < C; ++c) {
+          double ra = sqrt(fabs(a[c]) + eps), rb = sqrt(fabs(b[c]) + eps);
+          da[c] = sg * outer * ((ra - rb) / ra) * sgn(a[c]);
+          db[c] = sg * outer * (-(ra - rb) / rb) * sgn(b[c]);
+        }
+      return sg * f;
+    }
+    case NFP_CHISQUARED1:
+    case NFP_CHISQUARED2: {
+      double sg = m->similarity ? -1.0 : 1.0;
+      int one = m->measure == NFP_CHISQUARED1;
+      for (c = 0; c < C; ++c) {
+        double v = a[c] - b[c];
+        double w = fabs(a[c]) + (one ? fabs(b[c]) : 0.0) + eps;
+        f += v * v / w;
+        if (want) {
+          da[c] = sg * (2.0 * v / w - v * v * sgn(a[c]) / (w * w));
+          db[c] = sg * (-2.0 * v / w - (one ? v * v * sgn(b[c]) / (w * w) : 0.0));
+        }
+      }
+      return sg * f;
+    }
+    case NFP_GFC: {
+      double na = 0, nb = 0, num = 0;
+      for (c = 0; c < C; ++c) {
+        na += a[c] * a[c];
+        nb += b[c] * b[c];
+        num += a[c] * b[c];
+      }
+      na = sqrt(na);
+      nb = sqrt(nb);
+      double den = na * nb + eps; /* nfp.py:272 */
+      f = num / den;
+      double sg = m->similarity ? 1.0 : -1.0;
+      if (want)
+        for (c = 0; c < C; ++c) {
+          double ua = na > 0 ? a[c] / na : 0.0, ub = nb > 0 ? b[c] / nb : 0.0;
+          da[c] = sg * (b[c] / den - num / (den * den) * nb * ua);
+          db[c] = sg * (a[c] / den - num / (den * den) * na * ub);
+        }
+      return sg * f;
+    }
+    case NFP_PEARSON: {
+      double ma = 0, mb = 0, saa = 0, sbb = 0, sab = 0;
+      for (c = 0; c < C; ++c) {
+        ma += a[c];
+        mb += b[c];
+      }
+      ma /= C;
+      mb /= C;
+      for (c = 0; c < C; ++c) {
+        double ac = a[c] - ma, bc = b[c] - mb;
+        saa += ac * ac;
+        sbb += bc * bc;
+        sab += ac * bc;
+      }
+      double den = sqrt(saa * sbb + eps); /* nfp.py:289 */
+      f = sab / den;
+      double sg = m->similarity ? 1.0 : -1.0;
+      if (want)
+        for (c = 0; c < C; ++c) {
+          double ac = a[c] - ma, bc = b[c] - mb;
+          da[c] = sg * (bc / den - sab * ac * sbb / (den * den * den));
+          db[c] = sg * (ac / den - sab * bc * saa / (den * den * den));
+        }
+      return sg * f;
+    }
+    case NFP_JEFFREY: {
+      double sg = m->similarity ? -1.0 : 1.0;
+      for (c = 0; c < C; ++c) {
+        double ca = fabs(a[c]) + eps, cb = fabs(b[c]) + eps;
+        double l = log(ca / cb);
+        f += ca * l + cb * log(cb / ca);
+        if (want) {
+          da[c] = sg * (l + 1.0 - cb / ca) * sgn(a[c]);
+          db[c] = sg * (-l + 1.0 - ca / cb) * sgn(b[c]);
+        }
+      }
+      return sg * f;
+    }
+    case NFP_SMITH: {
+      double mn = 0, sa = 0, sb = 0;
+      for (c = 0; c < C; ++c) {
+        double A = fabs(a[c]), B = fabs(b[c]);
+        mn += A < B ? A : B;
+        sa += A;
+        sb += B;
+      }
+      double mm = (sa < sb ? sa : sb) + eps;
+      f = 1.0 - mn / mm; /* nfp.py:339 */
+      double sg = m->similarity ? 1.0 : -1.0;
+      if (want) {
+        double wa = sa < sb ? 1.0 : (sa == sb ? 0.5 : 0.0), wb = 1.0 - wa;
+        for (c = 0; c < C; ++c) {
+          double A = fabs(a[c]), B = fabs(b[c]);
+          double ta = A < B ? 1.0 : (A == B ? 0.5 : 0.0), tb = 1.0 - ta;
+          da[c] = sg * (-ta / mm + mn / (mm * mm) * wa) * sgn(a[c]);
+          db[c] = sg * (-tb / mm + mn / (mm * mm) * wb) * sgn(b[c]);
+        }
+      }
+      return sg * f;
+    }
+  }
+  return NAN;
+}
+
+static int measure_ok(int m) { return m >= 0 && m < NFP_MEASURE_COUNT; }
+
+/* ---- SharpenedCosine (nfp.py:344-374), including its batch-mixing broadcast --------
+ * cosine (B,N,H,W) is divided by a (B,1,N,H,W) norm product, which broadcasts to
+ * (B_i, B_j, N, H, W) with value num[j]/den[i]; .mean(dim=1) averages over j. */
+static int scs_forward_backward(const nfp_desc* d, const float* x, const float* go, float* out, float* gx_out) {
+  int N, Ho, Wo;
+  int rc = nfp_oracle_output_shape(d, &N, &Ho, &Wo);
+  if (rc) return rc;
+  const int B = d->B, C = d->C, k = 2 * d->R + 1;
+  const int64_t P = (int64_t)N * Ho * Wo;
+  double* num = (double*)malloc(sizeof(double) * B * P);
+  double* den = (double*)malloc(sizeof(double) * B * P);
+  double* gnum = (double*)calloc(B * P, sizeof(double));
+  double* gden = (double*)calloc(B * P, sizeof(double));
+  double* a = (double*)malloc(sizeof(double) * C * 2);
+  double* bb = a + C;
+  const double q = d->q_scs, p = d->p;
+  for (int b = 0; b < B; ++b)
+    for (int n = 0, t = 0; t < k * k; ++t) {
+      if (t == (k * k) / 2) continue;
+      for (int oy = 0; oy < Ho; ++oy)
+        for (int ox = 0; ox < Wo; ++ox) {
+          gather(d, x, b, tap_pixel(d, oy, ox, d->R, d->R), a);
+          gather(d, x, b, tap_pixel(d, oy, ox, t / k, t % k), bb);
+          double na = 0, nb = 0, dot = 0;
+          for (int c = 0; c < C; ++c) {
+            na += a[c] * a[c];
+            nb += bb[c] * bb[c];
+            dot += a[c] * bb[c];
+          }
+          int64_t i = (int64_t)b * P + ((int64_t)n * Ho + oy) * Wo + ox;
+          num[i] = dot;
+          den[i] = (sqrt(na) + q) * (sqrt(nb) + q);
+        }
+      ++n;
+    }
+  for (int i = 0; i < B; ++i)
+    for (int64_t e = 0; e < P; ++e) {
+      double acc = 0;
+      for (int j = 0; j < B; ++j) {
+        double c = num[j * P + e] / den[i * P + e];
+        double s = sgn(c) * pow(fabs(c), p);
+        if (isnan(s) || isinf(s)) s = 0.0;
+        if (!d->similarity) s = 1.0 - s;
+        acc += s;
+        if (go) {
+          /* d s / d c = p |c|^(p-1); nan_to_num passes grad only where finite */
+          double sv = sgn(c) * pow(fabs(c), p);
+          double dc = (isnan(sv) || isinf(sv)) ? 0.0 : p * pow(fabs(c), p - 1.0);
+          if (c == 0.0) dc = (p == 1.0) ? 1.0 : (p > 1.0 ? 0.0 : dc);
+          double g = (double)go[i * P + e] / B * (d->similarity ? 1.0 : -1.0) * dc;
+          gnum[j * P + e] += g / den[i * P + e];
+          gden[i * P + e] += -g * num[j * P + e] / (den[i * P + e] * den[i * P + e]);
+        }
+      }
+      if (out) out[i * P + e] = (float)(acc / B);
+    }
+  if (go && gx_out) {
+    int64_t HW = (int64_t)d->H * d->W;
+    double* gx = (double*)calloc((size_t)B * C * HW, sizeof(double));
+    double* ga = (double*)malloc(sizeof(double) * C * 2);
+    double* gb = ga + C;
+    for (int b = 0; b < B; ++b)
+      for (int n = 0, t = 0; t < k * k; ++t) {
+        if (t == (k * k) / 2) continue;
+        for (int oy = 0; oy < Ho; ++oy)
+          for (int ox = 0; ox < Wo; ++ox) {
+            int pa = tap_pixel(d, oy, ox, d->R, d->R), pb = tap_pixel(d, oy, ox, t / k, t % k);
+            gather(d, x, b, pa, a);
+            gather(d, x, b, pb, bb);
+            double na = 0, nb = 0;
+            for (int c = 0; c < C; ++c) {
+              na += a[c] * a[c];
+              nb += bb[c] * bb[c];
+            }
+            na = sqrt(na);
+            nb = sqrt(nb);
+            int64_t i = (int64_t)b * P + ((int64_t)n * Ho + oy) * Wo + ox;
+            for (int c = 0; c < C; ++c) {
+              ga[c] = gnum[i] * bb[c] + gden[i] * (nb + q) * (na > 0 ? a[c] / na : 0.0);
+              gb[c] = gnum[i] * a[c] + gden[i] * (na + q) * (nb > 0 ? bb[c] / nb : 0.0);
+            }
+            scatter_add(d, gx, b, pa, ga, 1.0);
+            scatter_add(d, gx, b, pb, gb, 1.0);
+          }
+        ++n;
+      }
+    for (int b = 0; b < B; ++b)
+      for (int c = 0; c < C; ++c)
+        for (int y = 0; y < d->H; ++y)
+          for (int xx = 0; xx < d->W; ++xx)
+            gx_out[(int64_t)b * d->sxB + (int64_t)c * d->sxC + (int64_t)y * d->sxH + (int64_t)xx * d->sxW] =
+                (float)gx[((int64_t)b * C + c) * HW + y * d->W + xx];
+    free(gx);
+    free(ga);
+  }
+  free(num);
+  free(den);
+  free(gnum);
+  free(gden);
+  free(a);
+  return NFP_OK;
+}
+
+/* ---- public oracle entry points -------------------------------------------------- */
+
+/* x: host float32 [B,C,H,W] by d->sx*;  out: host float32 [B,N,Ho,Wo] contiguous */
+int nfp_oracle_forward(const nfp_desc* d, const float* x, float* out) {
+  int N, Ho, Wo;
+  int rc = nfp_oracle_output_shape(d, &N, &Ho, &Wo);
+  if (rc) return rc;
+  if (!measure_ok(d->measure)) return NFP_E_INVALID;
+  if (d->measure == NFP_SCS) return scs_forward_backward(d, x, NULL, out, NULL);
+  const int k = 2 * d->R + 1, C = d->C;
+  pm m = {C, d->measure, d->similarity, d->diff_weights, (double)d->p, (double)d->eps};
+  double* a = (double*)malloc(sizeof(double) * C * 2);
+  double* b = a + C;
+  double* row = (double*)malloc(sizeof(double) * N);
+  for (int bi = 0; bi < d->B; ++bi)
+    for (int oy = 0; oy < Ho; ++oy)
+      for (int ox = 0; ox < Wo; ++ox) {
+        gather(d, x, bi, tap_pixel(d, oy, ox, d->R, d->R), a);
+        for (int n = 0, t = 0; t < k * k; ++t) {
+          if (t == (k * k) / 2) continue; /* centre skipped: nfp.py:66-67 */
+          gather(d, x, bi, tap_pixel(d, oy, ox, t / k, t % k), b);
+          row[n++] = pair_eval(&m, a, b, NULL, NULL);
+        }
+        if (d->measure == NFP_ATTENTION) { /* softmax over n: nfp.py:202-204 */
+          double mx = row[0], s = 0;
+          for (int n = 1; n < N; ++n) mx = row[n] > mx ? row[n] : mx;
+          for (int n = 0; n < N; ++n) s += (row[n] = exp(row[n] - mx));
+          for (int n = 0; n < N; ++n) row[n] = (d->similarity ? 1.0 : -1.0) * row[n] / s;
+        }
+        for (int n = 0; n < N; ++n) out[(((int64_t)bi * N + n) * Ho + oy) * Wo + ox] = (float)row[n];
+      }
+  free(a);
+  free(row);
+  return NFP_OK;
+}
+
+/* grad_x (host float32, strides of x) = d sum(out*grad_out) / dx */
+int nfp_oracle_backward(const nfp_desc* d, const float* x, const float* grad_out, float* grad_x) {
+  int N, Ho, Wo;
+  int rc = nfp_oracle_output_shape(d, &N, &Ho, &Wo);
+  if (rc) return rc;
+  if (!measure_ok(d->measure)) return NFP_E_INVALID;
+  if (d->measure == NFP_SCS) return scs_forward_backward(d, x, grad_out, NULL, grad_x);
+  const int k = 2 * d->R + 1, C = d->C;
+  const int64_t HW = (int64_t)d->H * d->W;
+  pm m = {C, d->measure, d->similarity, d->diff_weights, (double)d->p, (double)d->eps};
+  double* a = (double*)malloc(sizeof(double) * C * 4);
+  double *b = a + C, *da = a + 2 * C, *db = a + 3 * C;
+  double* row = (double*)malloc(sizeof(double) * 2 * N);
+  double* gr = row + N;
+  double* gx = (double*)calloc((size_t)d->B * C * HW, sizeof(double));
+  for (int bi = 0; bi < d->B; ++bi)
+    for (int oy = 0; oy < Ho; ++oy)
+      for (int ox = 0; ox < Wo; ++ox) {
+        int pa = tap_pixel(d, oy, ox, d->R, d->R);
+        gather(d, x, bi, pa, a);
+        for (int n = 0; n < N; ++n) gr[n] = (double)grad_out[(((int64_t)bi * N + n) * Ho + oy) * Wo + ox];
+        if (d->measure == NFP_ATTENTION) {
+          /* y = +-softmax(dots): g_dot_n = y_n * (g_n - sum_m g_m y_m) with y the plain softmax */
+          double mx = -INFINITY, s = 0, gy = 0;
+          for (int n = 0, t = 0; t < k * k; ++t) {
+            if (t == (k * k) / 2) continue;
+            gather(d, x, bi, tap_pixel(d, oy, ox, t / k, t % k), b);
+            row[n] = pair_eval(&m, a, b, NULL, NULL);
+            mx = row[n] > mx ? row[n] : mx;
+            ++n;
+          }
+          for (int n = 0; n < N; ++n) s += (row[n] = exp(row[n] - mx));
+          double sg = d->similarity ? 1.0 : -1.0;
+          for (int n = 0; n < N; ++n) {
+            row[n] /= s;
+            gy += sg * gr[n] * row[n];
+          }
+          for (int n = 0; n < N; ++n) gr[n] = row[n] * (sg * gr[n] - gy);
+        }
+        for (int n = 0, t = 0; t < k * k; ++t) {
+          if (t == (k * k) / 2) continue;
+          int pb = tap_pixel(d, oy, ox, t / k, t % k);
+          gather(d, x, bi, pb, b);
+          pair_eval(&m, a, b, da, db);
+          scatter_add(d, gx, bi, pa, da, gr[n]);
+          scatter_add(d, gx, bi, pb, db, gr[n]);
+          ++n;
+        }
+      }
+  for (int bi = 0; bi < d->B; ++bi)
+    for (int c = 0; c < C; ++c)
+      for (int y = 0; y < d->H; ++y)
+        for (int xx = 0; xx < d->W; ++xx)
+          grad_x[(int64_t)bi * d->sxB + (int64_t)c * d->sxC + (int64_t)y * d->sxH + (int64_t)xx * d->sxW] =
+              (float)gx[((int64_t)bi * C + c) * HW + y * d->W + xx];
+  free(a);
+  free(row);
+  free(gx);
+  return NFP_OK;
+}

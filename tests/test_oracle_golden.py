@@ -1,0 +1,53 @@
+"""Pin the CPU oracle (oracle/nfp_oracle.c) against the real reference's outputs.
+
+Every fixture in tests/golden/ was produced by tests/golden/make_golden.py from
+/root/reference/models/pooling/nfp.py (torch 2.10 CPU, fp32).  The oracle computes
+in double, so the residual is the REFERENCE's own fp32 rounding: bound 2e-6 relative
+to the tensor's max (observed <= 5e-7), 10x inside the 1e-5 parity bar.
+"""
+import numpy as np
+import pytest
+
+import cases as K
+from conftest import load_golden, rel_err, same_nan_pattern
+
+TOL = 2e-6
+
+
+@pytest.mark.parametrize("name", [c["name"] for c in K.CASES])
+def test_oracle_matches_reference(name, oracle_lib):
+    c = K.BY_NAME[name]
+    g = load_golden(name)
+    x = K.make_input(c)
+    out = oracle_lib.forward(x, **c["ctor"])
+    assert out.shape == g["out"].shape
+    assert same_nan_pattern(out, g["out"])
+    assert rel_err(np.nan_to_num(out), np.nan_to_num(g["out"])) <= TOL
+    go = K.make_grad_out(c, out.shape)
+    gx = oracle_lib.backward(x, go, **c["ctor"])
+    if "gx" in g:
+        assert same_nan_pattern(gx, g["gx"]), name
+        assert rel_err(np.nan_to_num(gx), np.nan_to_num(g["gx"])) <= TOL
+    else:
+        idx = K.gx_sample_index(gx.size)
+        assert rel_err(gx.reshape(-1)[idx], g["gx_sample"]) <= TOL
+        s = gx.astype(np.float64).sum(axis=(1, 2, 3))
+        a = np.abs(gx.astype(np.float64)).sum(axis=(1, 2, 3))
+        assert np.max(np.abs(s - g["gx_sum"]) / g["gx_abs_sum"]) <= TOL
+        assert np.max(np.abs(a - g["gx_abs_sum"]) / g["gx_abs_sum"]) <= TOL
+
+
+def test_oracle_strided_input_equals_contiguous(oracle_lib):
+    """channels-last strides give the same answer as NCHW (the oracle reads by strides)."""
+    import ctypes
+    c = K.BY_NAME["geo_cos_nonsquare"]
+    x = K.make_input(c)
+    B, C, H, W = x.shape
+    ref = oracle_lib.forward(x, **c["ctor"])
+    xl = np.ascontiguousarray(x.transpose(0, 2, 3, 1))  # NHWC memory
+    d = oracle_lib.make_desc(x.shape, strides=(H * W * C, 1, W * C, C), **c["ctor"])
+    out = np.empty_like(ref)
+    fp = ctypes.POINTER(ctypes.c_float)
+    rc = oracle_lib.lib().nfp_oracle_forward(ctypes.byref(d), xl.ctypes.data_as(fp), out.ctypes.data_as(fp))
+    assert rc == 0
+    assert np.array_equal(out, ref)
