@@ -1,0 +1,77 @@
+// nfp_common.h — shared device/host definitions for the gfx950 NFP kernels.
+//
+// Reference being replaced: models/pooling/nfp.py::NFPPooling (nfp.py:15-375).
+// The reference materialises [B,C*N,H',W'] with two frozen one-hot depthwise
+// convs (nfp.py:42-82) and reduces over C with ATen ops; here the neighbour
+// gather is an index map into an LDS-resident slab of x and nothing of size
+// [B,C,N,...] ever exists.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/nfp.h"
+
+namespace nfp {
+
+// Kernel parameter block (by value in kernarg).
+struct KP {
+  int B, C, H, W, P;  // P = H*W input pixels per channel
+  int R, k, N, pad, stride, dil, mode;
+  int Ho, Wo, O;  // O = Ho*Wo outputs per neighbour map
+  int measure, similarity, diff, dtype;
+  float p, eps, q_scs;
+  long long sB, sC, sH, sW;  // element strides of x / grad_x
+  int contig;                // x is NCHW-contiguous
+  // launch shape
+  int Cc;   // channels per LDS chunk
+  int G;    // fwd generic: channel lanes per output (power of two <= 64)
+  int Ow;   // outputs per workgroup (fwd) / per batch (bwd)
+  int Cwg;  // bwd: channels per workgroup
+  int Tc;   // bwd generic: channel lanes per output
+};
+
+__device__ __forceinline__ float bf16_to_f32(uint16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) {
+  // round-to-nearest-even, NaN kept a NaN
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+  return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+__device__ __forceinline__ float ldx(const void* x, long long i, int dtype) {
+  return dtype == NFP_F32 ? ((const float*)x)[i] : bf16_to_f32(((const uint16_t*)x)[i]);
+}
+__device__ __forceinline__ void stx(void* x, long long i, float v, int dtype) {
+  if (dtype == NFP_F32)
+    ((float*)x)[i] = v;
+  else
+    ((uint16_t*)x)[i] = f32_to_bf16(v);
+}
+
+// nn.Conv2d padding_mode index map (reflect: -i / 2(n-1)-i; replicate: clamp;
+// circular: wrap; zeros: -1 = the tap reads 0).
+__device__ __forceinline__ int map_index(int t, int n, int mode) {
+  if (t >= 0 && t < n) return t;
+  if (mode == NFP_PAD_REFLECT) return t < 0 ? -t : 2 * (n - 1) - t;
+  if (mode == NFP_PAD_REPLICATE) return t < 0 ? 0 : n - 1;
+  if (mode == NFP_PAD_CIRCULAR) {
+    int r = t % n;
+    return r < 0 ? r + n : r;
+  }
+  return -1;
+}
+// flat input pixel of kernel tap (ky,kx) for output o; -1 = zero padding
+__device__ __forceinline__ int tap_pixel(const KP& g, int o, int ky, int kx) {
+  int oy = o / g.Wo, ox = o - oy * g.Wo;
+  int y = map_index(oy * g.stride + ky * g.dil - g.pad, g.H, g.mode);
+  int x = map_index(ox * g.stride + kx * g.dil - g.pad, g.W, g.mode);
+  return (y < 0 || x < 0) ? -1 : y * g.W + x;
+}
+// neighbour n (row-major, centre skipped: nfp.py:64-67) -> tap (ky,kx)
+__device__ __forceinline__ int nbr_pixel(const KP& g, int o, int n) {
+  int t = n < (g.k * g.k) / 2 ? n : n + 1;
+  return tap_pixel(g, o, t / g.k, t - (t / g.k) * g.k);
+}
+
+__device__ __forceinline__ float sgnf(float v) { return (float)((v > 0.f) - (v < 0.f)); }
+
+}  // namespace nfp

@@ -1,0 +1,198 @@
+// nfp_hip.hip — C ABI of libnfp_hip.so (include/nfp.h) and kernel dispatch.
+//
+// Stands in for models/pooling/nfp.py::NFPPooling.forward (nfp.py:132-134) and its
+// autograd backward.  gfx950 only; no CPU path lives here — the library fails
+// loudly (NFP_E_HIP / NFP_E_UNSUPPORTED) rather than fall back.
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "nfp_generic.h"
+
+using namespace nfp;
+
+namespace {
+
+thread_local char g_err[512] = "";
+thread_local char g_variant[64] = "";
+std::atomic<uint64_t> g_launches{0};
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+int hip_ok(hipError_t e, const char* what) {
+  if (e == hipSuccess) return NFP_OK;
+  return fail(NFP_E_HIP, "%s: %s", what, hipGetErrorString(e));
+}
+
+constexpr int kLdsBudgetFwd = 64 * 1024;  // bytes of x chunk per forward workgroup
+constexpr int kLdsBudgetBwd = 48 * 1024;  // bytes of x chunk (and as much again of grad) per backward workgroup
+constexpr int kLdsMax = 160 * 1024;
+
+int floor_pow2(int v) {
+  int p = 1;
+  while (p * 2 <= v) p *= 2;
+  return p;
+}
+
+// Validate the descriptor the way nn.Conv2d / F.pad would and fill the kernel parameter block.
+int make_kp(const nfp_desc* d, KP* g) {
+  if (!d) return fail(NFP_E_INVALID, "null descriptor");
+  if (d->B < 0 || d->C < 1 || d->H < 1 || d->W < 1) return fail(NFP_E_INVALID, "bad shape [%d,%d,%d,%d]", d->B, d->C, d->H, d->W);
+  if (d->R < 1 || d->stride < 1 || d->dilation < 1 || d->pad < 0)
+    return fail(NFP_E_INVALID, "bad conv geometry R=%d stride=%d dilation=%d pad=%d", d->R, d->stride, d->dilation, d->pad);
+  if (d->pad_mode < 0 || d->pad_mode > 3) return fail(NFP_E_INVALID, "bad pad_mode %d", d->pad_mode);
+  if (d->measure < 0 || d->measure >= NFP_MEASURE_COUNT) return fail(NFP_E_INVALID, "bad measure %d", d->measure);
+  if (d->dtype != NFP_F32 && d->dtype != NFP_BF16) return fail(NFP_E_INVALID, "bad dtype %d", d->dtype);
+  const int k = 2 * d->R + 1;
+  const int span = d->dilation * (k - 1) + 1;
+  if (d->H + 2 * d->pad < span || d->W + 2 * d->pad < span)
+    return fail(NFP_E_INVALID, "kernel span %d exceeds padded input %dx%d", span, d->H + 2 * d->pad, d->W + 2 * d->pad);
+  if (d->pad_mode == NFP_PAD_REFLECT && (d->pad >= d->H || d->pad >= d->W))
+    return fail(NFP_E_INVALID, "reflect padding %d must be smaller than the input %dx%d", d->pad, d->H, d->W);
+  if (d->pad_mode == NFP_PAD_CIRCULAR && (d->pad > d->H || d->pad > d->W))
+    return fail(NFP_E_INVALID, "circular padding %d must not exceed the input %dx%d", d->pad, d->H, d->W);
+  memset(g, 0, sizeof(*g));
+  g->B = d->B; g->C = d->C; g->H = d->H; g->W = d->W; g->P = d->H * d->W;
+  g->R = d->R; g->k = k; g->N = k * k - 1; g->pad = d->pad; g->stride = d->stride; g->dil = d->dilation;
+  g->mode = d->pad_mode;
+  g->Ho = (d->H + 2 * d->pad - span) / d->stride + 1;
+  g->Wo = (d->W + 2 * d->pad - span) / d->stride + 1;
+  g->O = g->Ho * g->Wo;
+  g->measure = d->measure; g->similarity = d->similarity != 0; g->diff = d->diff_weights != 0; g->dtype = d->dtype;
+  g->p = d->p; g->eps = d->eps; g->q_scs = d->q_scs;
+  g->sB = d->sxB; g->sC = d->sxC; g->sH = d->sxH; g->sW = d->sxW;
+  g->contig = (d->sxW == 1 && d->sxH == d->W && d->sxC == (int64_t)d->H * d->W) ? 1 : 0;
+  if ((int64_t)g->P * 4 + 64 > kLdsMax)
+    return fail(NFP_E_UNSUPPORTED, "feature map %dx%d does not fit one LDS channel slab", d->H, d->W);
+  return NFP_OK;
+}
+
+int stats_of(int measure) {
+  switch (measure) {
+    case NFP_COSINE: return 1;
+    default: return 0;
+  }
+}
+
+template <typename K>
+int set_lds(K kernel, size_t bytes) {
+  if (bytes <= 64 * 1024) return NFP_OK;
+  return hip_ok(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes),
+                "hipFuncSetAttribute(max dynamic LDS)");
+}
+
+// ---- generic launches -----------------------------------------------------------------------
+template <int M>
+int launch_fwd_generic(KP g, const void* x, void* out, float* saved, hipStream_t st) {
+  g.Cc = kLdsBudgetFwd / (g.P * 4);
+  if (g.Cc < 1) g.Cc = 1;
+  if (g.Cc > g.C) g.Cc = g.C;
+  if (g.O <= 1024) {
+    g.Ow = g.O;
+    g.G = floor_pow2(1024 / g.O);
+    if (g.G > 64) g.G = 64;
+    if (g.G > floor_pow2(g.C)) g.G = floor_pow2(g.C);
+  } else {
+    g.Ow = 1024;
+    g.G = 1;
+  }
+  int T = ((g.Ow * g.G + 63) / 64) * 64;
+  size_t lds = (size_t)g.Cc * g.P * 4;
+  if (int rc = set_lds(fwd_generic<M>, lds)) return rc;
+  dim3 grid(g.B, (g.O + g.Ow - 1) / g.Ow, (g.N + kGroup - 1) / kGroup);
+  hipLaunchKernelGGL(fwd_generic<M>, grid, dim3(T), lds, st, g, x, out, saved);
+  g_launches++;
+  snprintf(g_variant, sizeof(g_variant), "fwd_generic");
+  return hip_ok(hipGetLastError(), "launch fwd_generic");
+}
+
+template <int M>
+int launch_bwd_generic(KP g, const void* x, const void* go, const void* out, const float* saved, void* gx,
+                       hipStream_t st) {
+  g.Cc = kLdsBudgetBwd / (g.P * 4);
+  if (g.Cc < 1) g.Cc = 1;
+  if (g.Cc > g.C) g.Cc = g.C;
+  // enough channel blocks to put >= 256 workgroups on the chip when the batch is small
+  int want = (256 + g.B - 1) / (g.B > 0 ? g.B : 1);
+  int nblk = (g.C + g.Cc - 1) / g.Cc;
+  if (nblk < want) {
+    nblk = want < g.C ? want : g.C;
+    g.Cc = (g.C + nblk - 1) / nblk;
+    if (g.Cc < 1) g.Cc = 1;
+  }
+  g.Cwg = g.Cc;
+  g.Ow = g.O < 1024 ? g.O : 1024;
+  g.Tc = 1024 / g.Ow;
+  if (g.Tc > g.Cc) g.Tc = g.Cc;
+  int T = ((g.Ow * g.Tc + 63) / 64) * 64;
+  size_t lds = ((size_t)((g.Cc * g.P + 3) & ~3) + (size_t)g.Cc * g.P) * 4;
+  if (int rc = set_lds(bwd_generic<M>, lds)) return rc;
+  dim3 grid(g.B, (g.C + g.Cwg - 1) / g.Cwg);
+  hipLaunchKernelGGL(bwd_generic<M>, grid, dim3(T), lds, st, g, x, go, out, saved, gx);
+  g_launches++;
+  snprintf(g_variant, sizeof(g_variant), "bwd_generic");
+  return hip_ok(hipGetLastError(), "launch bwd_generic");
+}
+
+}  // namespace
+
+extern "C" {
+
+int nfp_abi_version(void) { return NFP_ABI_VERSION; }
+const char* nfp_last_error(void) { return g_err; }
+const char* nfp_last_variant(void) { return g_variant; }
+uint64_t nfp_launch_count(void) { return g_launches.load(); }
+
+int nfp_output_shape(const nfp_desc* d, int32_t* N, int32_t* Ho, int32_t* Wo) {
+  KP g;
+  if (int rc = make_kp(d, &g)) return rc;
+  if (N) *N = g.N;
+  if (Ho) *Ho = g.Ho;
+  if (Wo) *Wo = g.Wo;
+  return NFP_OK;
+}
+
+int64_t nfp_saved_floats(const nfp_desc* d) {
+  KP g;
+  if (make_kp(d, &g)) return -1;
+  return (int64_t)stats_of(g.measure) * g.B * g.P;
+}
+
+int nfp_forward(const nfp_desc* d, const void* x, void* out, float* saved, void* hip_stream) {
+  KP g;
+  if (int rc = make_kp(d, &g)) return rc;
+  if (!x || !out) return fail(NFP_E_INVALID, "null tensor pointer");
+  if (g.B == 0) return NFP_OK;
+  hipStream_t st = (hipStream_t)hip_stream;
+  switch (g.measure) {
+    case NFP_COSINE: return launch_fwd_generic<NFP_COSINE>(g, x, out, saved, st);
+    case NFP_NORM: return launch_fwd_generic<NFP_NORM>(g, x, out, saved, st);
+    default: return fail(NFP_E_UNSUPPORTED, "measure %d has no HIP kernel yet", g.measure);
+  }
+}
+
+int nfp_backward(const nfp_desc* d, const void* x, const void* grad_out, const void* out, const float* saved,
+                 void* grad_x, void* hip_stream) {
+  KP g;
+  if (int rc = make_kp(d, &g)) return rc;
+  if (!x || !grad_out || !out || !grad_x) return fail(NFP_E_INVALID, "null tensor pointer");
+  if (stats_of(g.measure) > 0 && !saved) return fail(NFP_E_INVALID, "measure %d needs the saved state of nfp_forward", g.measure);
+  if (g.B == 0) return NFP_OK;
+  hipStream_t st = (hipStream_t)hip_stream;
+  switch (g.measure) {
+    case NFP_COSINE: return launch_bwd_generic<NFP_COSINE>(g, x, grad_out, out, saved, grad_x, st);
+    case NFP_NORM: return launch_bwd_generic<NFP_NORM>(g, x, grad_out, out, saved, grad_x, st);
+    default: return fail(NFP_E_UNSUPPORTED, "measure %d has no HIP kernel yet", g.measure);
+  }
+}
+
+}  // extern "C"

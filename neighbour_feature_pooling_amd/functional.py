@@ -1,0 +1,115 @@
+"""Functional NFP: `nfp(x, cfg)` — the autograd op behind NFPPooling.forward.
+
+CUDA tensors go through libnfp_hip.so (include/nfp.h) — one fused forward kernel,
+one fused backward kernel, saved state = the output map plus one float per input
+pixel.  Nothing else can serve a CUDA tensor: if the library is missing or refuses
+the configuration the call raises.  CPU tensors use `_host.nfp_host` (see there).
+"""
+import ctypes
+from dataclasses import dataclass
+
+import torch
+
+from . import _abi
+from ._host import nfp_host
+
+
+@dataclass(frozen=True)
+class NfpConfig:
+    """Constructor arguments of NFPPooling that define the op (nfp.py:16-39)."""
+    R: int = 1
+    measure: str = "norm"          # lower-cased name (nfp.py:21)
+    p: float = 1
+    stride: int = 1
+    padding: int = 0
+    dilation: int = 1
+    padding_mode: str = "reflect"
+    similarity: bool = True
+    eps: float = 1e-6
+    q_scs: float = 1e-6
+    diff_weights: bool = True      # raw measure string in ['norm','rmse','mahalanobis'] (nfp.py:74)
+
+    @property
+    def kernel_size(self):
+        return 2 * self.R + 1
+
+    @property
+    def out_channels(self):
+        return self.kernel_size ** 2 - 1
+
+
+_DTYPES = {torch.float32: _abi.F32, torch.bfloat16: _abi.BF16}
+
+
+def _dense(x):
+    """x as either NCHW-contiguous or channels-last-contiguous (read in place by strides)."""
+    if x.is_contiguous() or x.is_contiguous(memory_format=torch.channels_last):
+        return x
+    return x.contiguous()
+
+
+def make_desc(x, cfg):
+    if x.dtype not in _DTYPES:
+        raise _abi.NfpUnsupported(f"NFP HIP kernels take float32 or bfloat16 feature maps, got {x.dtype}")
+    d = _abi.NfpDesc()
+    d.B, d.C, d.H, d.W = x.shape
+    d.R, d.pad, d.stride, d.dilation = cfg.R, cfg.padding, cfg.stride, cfg.dilation
+    d.pad_mode = _abi.PAD_MODES.index(cfg.padding_mode)
+    d.measure = _abi.measure_id(cfg.measure)
+    d.similarity = int(bool(cfg.similarity))
+    d.diff_weights = int(bool(cfg.diff_weights))
+    d.dtype = _DTYPES[x.dtype]
+    d.p, d.eps, d.q_scs = float(cfg.p), float(cfg.eps), float(cfg.q_scs)
+    d.sxB, d.sxC, d.sxH, d.sxW = x.stride()
+    return d
+
+
+def output_shape(d):
+    L = _abi.load()
+    n, ho, wo = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+    _abi.check(L.nfp_output_shape(ctypes.byref(d), ctypes.byref(n), ctypes.byref(ho), ctypes.byref(wo)))
+    return d.B, n.value, ho.value, wo.value
+
+
+class _NfpHip(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, cfg):
+        L = _abi.load()
+        x = _dense(x)
+        d = make_desc(x, cfg)
+        need_grad = ctx.needs_input_grad[0]
+        with torch.cuda.device(x.device):
+            out = torch.empty(output_shape(d), dtype=x.dtype, device=x.device)
+            ns = L.nfp_saved_floats(ctypes.byref(d)) if need_grad else 0
+            saved = torch.empty(max(ns, 0), dtype=torch.float32, device=x.device)
+            stream = torch.cuda.current_stream(x.device).cuda_stream
+            _abi.check(L.nfp_forward(ctypes.byref(d), x.data_ptr(), out.data_ptr(),
+                                     saved.data_ptr() if ns > 0 else None, stream))
+        ctx.desc = d
+        ctx.save_for_backward(x, out, saved)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_out):
+        x, out, saved = ctx.saved_tensors
+        L = _abi.load()
+        d = ctx.desc
+        go = grad_out.contiguous()
+        if go.dtype != x.dtype:
+            go = go.to(x.dtype)
+        with torch.cuda.device(x.device):
+            gx = torch.empty_like(x)  # same strides as x (dense NCHW or channels-last)
+            stream = torch.cuda.current_stream(x.device).cuda_stream
+            _abi.check(L.nfp_backward(ctypes.byref(d), x.data_ptr(), go.data_ptr(), out.data_ptr(),
+                                      saved.data_ptr() if saved.numel() else None, gx.data_ptr(), stream))
+        return gx, None
+
+
+def nfp(x, cfg):
+    """[B,C,H,W] -> [B, k*k-1, H', W'] neighbour-similarity maps (NFPPooling.forward, nfp.py:132-134)."""
+    if x.dim() != 4:
+        raise RuntimeError(f"NFP expects a 4-D [B,C,H,W] feature map, got {tuple(x.shape)}")
+    if x.is_cuda:
+        return _NfpHip.apply(x, cfg)
+    return nfp_host(x, cfg)

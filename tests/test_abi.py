@@ -1,0 +1,98 @@
+"""C-ABI checks that need no GPU: the library loads, exports every symbol include/nfp.h
+declares, and its host-side validation / shape arithmetic matches the reference's conv."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+from neighbour_feature_pooling_amd import _abi
+from neighbour_feature_pooling_amd.build import build_hip
+
+
+@pytest.fixture(scope="module")
+def lib():
+    build_hip()
+    return _abi.load()
+
+
+def declared_functions():
+    src = open(os.path.join(ROOT, "include", "nfp.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(nfp_[a-z_]+)\s*\(", src)))
+
+
+def test_exports_every_declared_symbol(lib):
+    names = declared_functions()
+    assert len(names) >= 8
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/nfp.h but not exported"
+    assert sorted(_abi.EXPORTS) == names
+
+
+def test_abi_version_matches_header(lib):
+    src = open(os.path.join(ROOT, "include", "nfp.h")).read()
+    v = int(re.search(r"#define NFP_ABI_VERSION (\d+)", src).group(1))
+    assert lib.nfp_abi_version() == v == _abi.ABI_VERSION
+
+
+def test_desc_layout_matches_header():
+    # 13 int32 + 3 float + 4 int64, naturally aligned
+    assert ctypes.sizeof(_abi.NfpDesc) == 13 * 4 + 3 * 4 + 4 * 8
+    assert _abi.NfpDesc.sxB.offset == 64
+
+
+def _desc(shape, R=1, pad=1, stride=1, dil=1, mode="reflect", measure="cosine"):
+    d = _abi.NfpDesc()
+    d.B, d.C, d.H, d.W = shape
+    d.R, d.pad, d.stride, d.dilation = R, pad, stride, dil
+    d.pad_mode = _abi.PAD_MODES.index(mode)
+    d.measure = _abi.measure_id(measure)
+    d.similarity, d.diff_weights, d.dtype = 1, 0, 0
+    d.p, d.eps, d.q_scs = 2.0, 1e-6, 1e-6
+    B, C, H, W = shape
+    d.sxB, d.sxC, d.sxH, d.sxW = C * H * W, H * W, W, 1
+    return d
+
+
+@pytest.mark.parametrize("shape,kw,expect", [
+    ((64, 512, 7, 7), dict(), (8, 7, 7)),
+    ((2, 64, 14, 14), dict(), (8, 14, 14)),
+    ((8, 512, 2, 2), dict(), (8, 2, 2)),
+    ((4, 192, 14, 14), dict(R=2, pad=2), (24, 14, 14)),
+    ((1, 32, 5, 5), dict(pad=0), (8, 3, 3)),
+    ((2, 16, 9, 9), dict(stride=2), (8, 5, 5)),
+    ((2, 8, 11, 10), dict(pad=0, stride=2, dil=2), (8, 4, 3)),
+    ((1, 8, 9, 9), dict(R=3, pad=3), (48, 9, 9)),
+])
+def test_output_shape(lib, shape, kw, expect):
+    d = _desc(shape, **kw)
+    n, ho, wo = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+    assert lib.nfp_output_shape(ctypes.byref(d), ctypes.byref(n), ctypes.byref(ho), ctypes.byref(wo)) == 0
+    assert (n.value, ho.value, wo.value) == expect
+
+
+def test_invalid_descriptors_are_refused(lib):
+    n = ctypes.c_int32()
+    bad = [
+        _desc((1, 4, 2, 2), pad=2),                 # reflect pad >= size (torch raises too)
+        _desc((1, 4, 2, 2), R=2, pad=0),            # kernel larger than input
+        _desc((1, 4, 5, 5), stride=0),
+        _desc((1, 0, 5, 5)),
+    ]
+    for d in bad:
+        rc = lib.nfp_output_shape(ctypes.byref(d), ctypes.byref(n), ctypes.byref(n), ctypes.byref(n))
+        assert rc == -1
+        assert lib.nfp_last_error()
+    d = _desc((1, 4, 5, 5))
+    d.measure = 99
+    assert lib.nfp_forward(ctypes.byref(d), None, None, None, None) == -1
+    d = _desc((1, 4, 5, 5))
+    assert lib.nfp_forward(ctypes.byref(d), None, None, None, None) == -1  # null pointers
+    assert b"null" in lib.nfp_last_error()
+
+
+def test_saved_floats(lib):
+    assert lib.nfp_saved_floats(ctypes.byref(_desc((64, 512, 7, 7)))) == 64 * 49
+    assert lib.nfp_saved_floats(ctypes.byref(_desc((4, 192, 14, 14), R=2, pad=2, measure="norm"))) == 0

@@ -51,3 +51,25 @@ def test_oracle_strided_input_equals_contiguous(oracle_lib):
     rc = oracle_lib.lib().nfp_oracle_forward(ctypes.byref(d), xl.ctypes.data_as(fp), out.ctypes.data_as(fp))
     assert rc == 0
     assert np.array_equal(out, ref)
+
+
+@pytest.mark.parametrize("name", ["c1_cos_k3_2x64x14x14", "c2_cos_k3_4x512x7x7", "c3_cos_k3_8x512x2x2",
+                                  "c5_l2_k5_4x192x14x14", "geo_cos_stride2_dil2_pad0", "geo_l2_zeros",
+                                  "edge_cos_tiny_norms", "edge_cos_dissimilarity"])
+def test_unfold_torch_restatement_matches_reference(name):
+    """oracle/unfold_torch.py (bench.py's timed CPU baseline) reproduces the reference."""
+    import torch
+    from oracle.unfold_torch import UnfoldNFP
+    c = K.BY_NAME[name]
+    g = load_golden(name)
+    ctor = dict(c["ctor"])
+    x = torch.from_numpy(K.make_input(c)).requires_grad_(True)
+    m = UnfoldNFP(c["shape"][1], **ctor)
+    out = m(x)
+    assert rel_err(out.detach().numpy(), g["out"]) <= 1e-6
+    out.backward(torch.from_numpy(K.make_grad_out(c, tuple(out.shape))))
+    gx = x.grad.numpy()
+    if "gx" in g:
+        assert rel_err(gx, g["gx"]) <= 1e-6
+    else:
+        assert rel_err(gx.reshape(-1)[K.gx_sample_index(gx.size)], g["gx_sample"]) <= 1e-6
