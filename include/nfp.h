@@ -109,8 +109,8 @@ int nfp_backward(const nfp_desc* d, const void* x, const void* grad_out, const v
  * the HIP path, not a fallback, produced a result). */
 uint64_t nfp_launch_count(void);
 
-/* Name of the kernel variant the last nfp_forward / nfp_backward on this
- * thread selected (for bench / profile bookkeeping). */
+/* Name of the kernel variant the last nfp_forward / nfp_backward of this
+ * process selected (for bench / profile bookkeeping). */
 const char* nfp_last_variant(void);
 
 #ifdef __cplusplus

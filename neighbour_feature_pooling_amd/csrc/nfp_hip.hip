@@ -17,7 +17,7 @@ using namespace nfp;
 namespace {
 
 thread_local char g_err[512] = "";
-thread_local char g_variant[64] = "";
+char g_variant[64] = "";  // process-wide: backward runs on an autograd worker thread
 std::atomic<uint64_t> g_launches{0};
 
 int fail(int code, const char* fmt, ...) {
