@@ -10,6 +10,9 @@
 #include <cstdio>
 #include <cstring>
 
+#include <cstdlib>
+
+#include "nfp_fast.h"
 #include "nfp_generic.h"
 
 using namespace nfp;
@@ -143,6 +146,86 @@ int launch_bwd_generic(KP g, const void* x, const void* go, const void* out, con
   return hip_ok(hipGetLastError(), "launch bwd_generic");
 }
 
+// ---- fast-path launches (nfp_fast.h) ----------------------------------------------------------
+constexpr int kSlabBudgetFwd = 128 * 1024;
+constexpr int kSlabBudgetBwd = 96 * 1024;
+
+bool force_generic() {
+  const char* e = getenv("NFP_FORCE_GENERIC");
+  return e && e[0] == '1';
+}
+
+// Which calls the hot-path kernels serve; everything else runs on the generic kernels.
+bool fast_ok(const KP& g, const void* x, const void* gx) {
+  if (force_generic()) return false;
+  if (g.stride != 1 || g.dil != 1 || g.pad != g.R || g.mode == NFP_PAD_CIRCULAR) return false;
+  if (g.R != 1 && g.R != 2) return false;
+  if ((g.C & 3) || g.P > kBwdThreads) return false;
+  if (!(g.measure == NFP_COSINE || (g.measure == NFP_NORM && g.p == 2.f))) return false;
+  const bool nhwc = g.sC == 1 && g.sW == g.C && g.sH == (long long)g.W * g.C;
+  if (!g.contig && !nhwc) return false;
+  if (!g.contig) {  // vector loads of 4 channels need natural alignment
+    const uintptr_t m = g.dtype == NFP_F32 ? 15 : 7;
+    if (((uintptr_t)x & m) || ((uintptr_t)gx & m) || ((g.sB * (g.dtype == NFP_F32 ? 4 : 2)) & m)) return false;
+  }
+  return true;
+}
+
+int round4(int v) { return (v + 3) & ~3; }
+
+template <int R, int M>
+int launch_fwd_fast(KP g, const void* x, void* out, float* saved, hipStream_t st) {
+  constexpr int NF = Win<R>::NF;
+  g.G = kFwdThreads / g.P;
+  if (g.G < 1) g.G = 1;
+  if (g.G > g.C / 4) g.G = g.C / 4;
+  int cmax = 4 * g.G * kMaxK;
+  int cbud = (kSlabBudgetFwd / (g.P * 16)) * 4;
+  if (cmax > cbud) cmax = cbud;
+  int nch = (g.C + cmax - 1) / cmax;
+  g.Cc = round4((g.C + nch - 1) / nch);
+  int T = ((g.P * g.G + 63) / 64) * 64;
+  size_t slab = (size_t)(g.Cc / 4) * g.P * 16;
+  size_t red = (size_t)(g.G + 1) * (NF + 1) * g.P * 4;
+  size_t lds = slab > red ? slab : red;
+  if (lds > (size_t)kLdsMax) return fail(NFP_E_UNSUPPORTED, "fwd_fast: LDS %zu", lds);
+  if (int rc = set_lds(fwd_fast<R, M>, lds)) return rc;
+  hipLaunchKernelGGL((fwd_fast<R, M>), dim3(g.B), dim3(T), lds, st, g, x, out, saved);
+  g_launches++;
+  snprintf(g_variant, sizeof(g_variant), "fwd_fast<R%d,%s>", R, M == NFP_COSINE ? "cos" : "l2");
+  return hip_ok(hipGetLastError(), "launch fwd_fast");
+}
+
+template <int R, int M>
+int launch_bwd_fast(KP g, const void* x, const void* go, const void* out, const float* saved, void* gx,
+                    hipStream_t st) {
+  constexpr int N = Win<R>::N, K2 = Win<R>::K2;
+  int S = (256 + g.B - 1) / g.B;  // channel blocks per image so that >= 256 workgroups exist
+  if (S > g.C / 4) S = g.C / 4;
+  if (S < 1) S = 1;
+  g.Cwg = round4((g.C + S - 1) / S);
+  S = (g.C + g.Cwg - 1) / g.Cwg;
+  g.G = kBwdThreads / g.P;
+  if (g.G < 1) g.G = 1;
+  if (g.G > g.Cwg / 4) g.G = g.Cwg / 4;
+  size_t wt = (size_t)g.P * K2 * 4;
+  size_t tables = (size_t)(3 * g.P * N + g.P * K2) * 4;
+  int cmax = 4 * g.G * kMaxK;
+  int cbud = (kSlabBudgetBwd / (g.P * 16)) * 4;
+  if (cmax > cbud) cmax = cbud;
+  int nch = (g.Cwg + cmax - 1) / cmax;
+  g.Cc = round4((g.Cwg + nch - 1) / nch);
+  size_t slab = (size_t)(g.Cc / 4) * g.P * 16;
+  size_t lds = ((wt + 15) & ~(size_t)15) + (slab > tables ? slab : tables);
+  if (lds > (size_t)kLdsMax) return fail(NFP_E_UNSUPPORTED, "bwd_fast: LDS %zu", lds);
+  int T = ((g.P * g.G + 63) / 64) * 64;
+  if (int rc = set_lds(bwd_fast<R, M>, lds)) return rc;
+  hipLaunchKernelGGL((bwd_fast<R, M>), dim3(g.B, S), dim3(T), lds, st, g, x, go, out, saved, gx);
+  g_launches++;
+  snprintf(g_variant, sizeof(g_variant), "bwd_fast<R%d,%s>", R, M == NFP_COSINE ? "cos" : "l2");
+  return hip_ok(hipGetLastError(), "launch bwd_fast");
+}
+
 }  // namespace
 
 extern "C" {
@@ -173,6 +256,13 @@ int nfp_forward(const nfp_desc* d, const void* x, void* out, float* saved, void*
   if (!x || !out) return fail(NFP_E_INVALID, "null tensor pointer");
   if (g.B == 0) return NFP_OK;
   hipStream_t st = (hipStream_t)hip_stream;
+  if (fast_ok(g, x, x)) {
+    if (g.measure == NFP_COSINE)
+      return g.R == 1 ? launch_fwd_fast<1, NFP_COSINE>(g, x, out, saved, st)
+                      : launch_fwd_fast<2, NFP_COSINE>(g, x, out, saved, st);
+    return g.R == 1 ? launch_fwd_fast<1, NFP_NORM>(g, x, out, saved, st)
+                    : launch_fwd_fast<2, NFP_NORM>(g, x, out, saved, st);
+  }
   switch (g.measure) {
     case NFP_COSINE: return launch_fwd_generic<NFP_COSINE>(g, x, out, saved, st);
     case NFP_NORM: return launch_fwd_generic<NFP_NORM>(g, x, out, saved, st);
@@ -188,6 +278,13 @@ int nfp_backward(const nfp_desc* d, const void* x, const void* grad_out, const v
   if (stats_of(g.measure) > 0 && !saved) return fail(NFP_E_INVALID, "measure %d needs the saved state of nfp_forward", g.measure);
   if (g.B == 0) return NFP_OK;
   hipStream_t st = (hipStream_t)hip_stream;
+  if (fast_ok(g, x, grad_x)) {
+    if (g.measure == NFP_COSINE)
+      return g.R == 1 ? launch_bwd_fast<1, NFP_COSINE>(g, x, grad_out, out, saved, grad_x, st)
+                      : launch_bwd_fast<2, NFP_COSINE>(g, x, grad_out, out, saved, grad_x, st);
+    return g.R == 1 ? launch_bwd_fast<1, NFP_NORM>(g, x, grad_out, out, saved, grad_x, st)
+                    : launch_bwd_fast<2, NFP_NORM>(g, x, grad_out, out, saved, grad_x, st);
+  }
   switch (g.measure) {
     case NFP_COSINE: return launch_bwd_generic<NFP_COSINE>(g, x, grad_out, out, saved, grad_x, st);
     case NFP_NORM: return launch_bwd_generic<NFP_NORM>(g, x, grad_out, out, saved, grad_x, st);

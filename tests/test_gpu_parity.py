@@ -58,8 +58,16 @@ def _supported(c):
     return c["ctor"]["measure"].lower() in HIP_MEASURES
 
 
+@pytest.fixture(params=["auto", "generic"])
+def variant(request, monkeypatch):
+    """'auto' = the dispatcher's choice (hot-path kernels where they apply); 'generic' forces the
+    any-geometry kernels, so both implementations are held to the same bar on every case."""
+    monkeypatch.setenv("NFP_FORCE_GENERIC", "1" if request.param == "generic" else "0")
+    return request.param
+
+
 @pytest.mark.parametrize("name", [c["name"] for c in K.CASES if _supported(c)])
-def test_hip_matches_reference_golden(name, dev):
+def test_hip_matches_reference_golden(name, dev, variant):
     c = K.BY_NAME[name]
     g = load_golden(name)
     out, gx, _ = run_hip(c, dev)
@@ -77,7 +85,7 @@ def test_hip_matches_reference_golden(name, dev):
 
 
 @pytest.mark.parametrize("name", [c["name"] for c in K.CASES if _supported(c)])
-def test_hip_matches_oracle(name, dev, oracle_lib):
+def test_hip_matches_oracle(name, dev, oracle_lib, variant):
     c = K.BY_NAME[name]
     x = K.make_input(c)
     out, gx, go = run_hip(c, dev)
@@ -89,7 +97,7 @@ def test_hip_matches_oracle(name, dev, oracle_lib):
 
 @pytest.mark.parametrize("name", ["c1_cos_k3_2x64x14x14", "c2_cos_k3_4x512x7x7", "c5_l2_k5_4x192x14x14",
                                   "geo_cos_stride2", "geo_cos_circular", "geo_l2_zeros", "cos_k5_selfpairs_2x24x5x5"])
-def test_channels_last_input_read_in_place(name, dev):
+def test_channels_last_input_read_in_place(name, dev, variant):
     c = K.BY_NAME[name]
     out0, gx0, _ = run_hip(c, dev)
     out1, gx1, _ = run_hip(c, dev, channels_last=True)
@@ -98,7 +106,7 @@ def test_channels_last_input_read_in_place(name, dev):
 
 
 @pytest.mark.parametrize("name", ["c5_l2_k5_bf16in_4x192x14x14", "c5_cos_k5_2x192x14x14", "c2_cos_k3_4x512x7x7"])
-def test_bf16_storage_fp32_accumulate(name, dev, oracle_lib):
+def test_bf16_storage_fp32_accumulate(name, dev, oracle_lib, variant):
     """bf16 load/store, f32 arithmetic: compare with the oracle run on the SAME bf16-rounded inputs."""
     c = K.BY_NAME[name]
     xb = K._bf16_round(K.make_input(c))
@@ -137,6 +145,17 @@ def headline(dev):
     return m, x
 
 
+def test_headline_uses_hot_path_kernels(headline):
+    from neighbour_feature_pooling_amd import _abi
+    m, x = headline
+    x = x.clone().requires_grad_(True)
+    out = m(x)
+    assert _abi.load().nfp_last_variant().decode().startswith("fwd_fast")
+    out.sum().backward()
+    torch.cuda.synchronize()
+    assert _abi.load().nfp_last_variant().decode().startswith("bwd_fast")
+
+
 def test_headline_bounds_and_symmetry(headline):
     m, x = headline
     out = m(x)
@@ -166,7 +185,7 @@ def test_headline_dissimilarity_is_one_minus(headline):
     from neighbour_feature_pooling_amd import NFPPooling
     m, x = headline
     md = NFPPooling(512, R=1, measure="cosine", padding=1, similarity=False)
-    assert (md(x) - (1 - m(x))).abs().max().item() <= 1e-7
+    assert (md(x) - (1 - m(x))).abs().max().item() <= 2.4e-7  # one rounding of 1 - s
 
 
 def test_headline_backward_linear_in_grad_out_and_scale_invariant(headline):
