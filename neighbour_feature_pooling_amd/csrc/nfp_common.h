@@ -28,6 +28,8 @@ struct KP {
   int Ow;   // outputs per workgroup (fwd) / per batch (bwd)
   int Cwg;  // bwd: channels per workgroup
   int Tc;   // bwd generic: channel lanes per output
+  // host-computed reciprocals (hot path: exact small-integer division by float multiply)
+  float invP, invW, invNQ, invPT, inv_eps;
 };
 
 __device__ __forceinline__ float bf16_to_f32(uint16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
@@ -59,6 +61,13 @@ __device__ __forceinline__ int map_index(int t, int n, int mode) {
   }
   return -1;
 }
+// branch-free form for zeros / reflect / replicate (the hot path never sees circular)
+__device__ __forceinline__ int map_index_bf(int t, int n, int mode) {
+  const int refl = t < 0 ? -t : (t >= n ? 2 * (n - 1) - t : t);
+  const int repl = min(max(t, 0), n - 1);
+  const int zero = (t >= 0 && t < n) ? t : -1;
+  return mode == NFP_PAD_REFLECT ? refl : (mode == NFP_PAD_REPLICATE ? repl : zero);
+}
 // flat input pixel of kernel tap (ky,kx) for output o; -1 = zero padding
 __device__ __forceinline__ int tap_pixel(const KP& g, int o, int ky, int kx) {
   int oy = o / g.Wo, ox = o - oy * g.Wo;
@@ -71,6 +80,26 @@ __device__ __forceinline__ int nbr_pixel(const KP& g, int o, int n) {
   int t = n < (g.k * g.k) / 2 ? n : n + 1;
   return tap_pixel(g, o, t / g.k, t - (t / g.k) * g.k);
 }
+
+// Diagnostic build only (-DNFP_STAMPS, scripts/diag_stamps.py): thread 0 of every workgroup records
+// {shader clock, 100 MHz wall clock} at phase boundaries into a buffer nothing else reads.
+#ifdef NFP_STAMPS
+__device__ unsigned long long* nfp_stamp_buf = nullptr;
+// The buffer pointer is read ONCE (a vector load + wait at kernel entry); a stamp is then one
+// s_memtime/s_memrealtime pair and two stores, with no vmcnt wait, so loads in flight stay in flight.
+#define NFP_STAMP_INIT() unsigned long long* nfp_sb_ = nfp_stamp_buf
+#define NFP_STAMP(id)                                                                        \
+  do {                                                                                       \
+    if (threadIdx.x == 0 && nfp_sb_) {                                                       \
+      unsigned long long wg = blockIdx.x + (unsigned long long)gridDim.x * blockIdx.y;       \
+      nfp_sb_[(wg * 16 + (id)) * 2] = __builtin_amdgcn_s_memtime();                         \
+      nfp_sb_[(wg * 16 + (id)) * 2 + 1] = __builtin_amdgcn_s_memrealtime();                 \
+    }                                                                                        \
+  } while (0)
+#else
+#define NFP_STAMP_INIT() do { } while (0)
+#define NFP_STAMP(id) do { } while (0)
+#endif
 
 __device__ __forceinline__ float sgnf(float v) { return (float)((v > 0.f) - (v < 0.f)); }
 

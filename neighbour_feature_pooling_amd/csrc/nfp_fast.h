@@ -1,15 +1,15 @@
 // nfp_fast.h — the hot-path kernels: stride 1, dilation 1, padding == R ("same" maps, every
 // in-tree caller: NFP_Pooling.py:14, resnet18.py:20, texture_pooling.py:232,302), padding_mode
 // zeros / reflect / replicate, cosine (nfp.py:150-159) and L2 = Norm p=2 (nfp.py:141-148),
-// C % 4 == 0, H*W <= 1024, NCHW or channels-last.
+// C % 4 == 0, H*W <= 512, NCHW or channels-last.
 //
 // HBM/LDS layout.  A workgroup owns one image (forward) or one image x channel block
 // (backward).  x[b, c0:c0+cc] is staged ONCE into LDS as float4[cc/4][P]: four consecutive
 // channels of one pixel share a 16-byte slot, so every neighbour access is one ds_read_b128
-// at a compile-time pixel offset from the thread's own slot.  Thread (p, lane) = (t % P, t / P)
-// owns pixel p for channel quads lane, lane+G, ...; the same mapping stages, computes and
-// (backward) stores, and consecutive threads touch consecutive pixels (coalesced, no bank
-// conflicts).
+// at a fixed pixel offset from the thread's own slot.  NCHW input is staged in 4-channel x
+// 4-pixel blocks (four 16-byte loads along the pixel axis, transposed in registers, four
+// ds_write_b128); channels-last input is one 16-byte load per slot.  Compute thread
+// (p, lane) = (t % P, t / P) owns pixel p for channel quads lane, lane+G, ...
 //
 // Forward: half stencil.  sim(p,q) is symmetric, so only the N/2 "forward" in-image pairs
 // (dy>0, or dy==0 && dx>0) plus |x_p|^2 are summed over channels; the k*k-1 outputs of a
@@ -27,10 +27,16 @@
 #pragma once
 #include "nfp_measures.h"
 
+#ifndef NFP_ABLATE
+#define NFP_ABLATE 0  // diagnostic builds only (scripts/diag_ablate.py): bit mask of phases to skip
+#endif
+
 namespace nfp {
 
-constexpr int kMaxK = 8;  // channel quads staged per thread per chunk
-constexpr int kFwdThreads = 1024;
+constexpr int kRB = 3;    // NCHW staging: 4x4 blocks per thread per chunk
+constexpr int kRT = 2;    // NCHW staging: tail (P % 4) pixel slots per thread per chunk
+constexpr int kRN = 8;    // channels-last staging: slots per thread per chunk
+constexpr int kFwdThreads = 512;   // every instruction costs (waves per SIMD) x 2 clk of CU issue time
 constexpr int kBwdThreads = 512;  // backward keeps (2R+1)^2 weights + offsets + staged x in registers
 
 template <int R>
@@ -55,144 +61,317 @@ __device__ __forceinline__ int fidx(int dy, int dx) {
   return dy == 0 ? dx - 1 : R + (dy - 1) * (2 * R + 1) + (dx + R);
 }
 
-__device__ __forceinline__ float4 ld4(const void* x, const KP& g, bool nhwc, long long img, int c, int p) {
-  // four consecutive channels c..c+3 of pixel p
-  float4 v;
-  if (g.dtype == NFP_F32) {
-    const float* s = (const float*)x + img;
-    if (nhwc) {
-      v = *(const float4*)(s + (long long)p * g.C + c);
-    } else {
-      const float* q = s + (long long)c * g.P + p;
-      v.x = q[0];
-      v.y = q[g.P];
-      v.z = q[2 * g.P];
-      v.w = q[3 * g.P];
-    }
-  } else {
-    const uint16_t* s = (const uint16_t*)x + img;
-    if (nhwc) {
-      uint2 u = *(const uint2*)(s + (long long)p * g.C + c);
-      v.x = __uint_as_float(u.x << 16);
-      v.y = __uint_as_float(u.x & 0xffff0000u);
-      v.z = __uint_as_float(u.y << 16);
-      v.w = __uint_as_float(u.y & 0xffff0000u);
-    } else {
-      const uint16_t* q = s + (long long)c * g.P + p;
-      v.x = bf16_to_f32(q[0]);
-      v.y = bf16_to_f32(q[g.P]);
-      v.z = bf16_to_f32(q[2 * g.P]);
-      v.w = bf16_to_f32(q[3 * g.P]);
+// Per-thread neighbour maps for stride 1 / dilation 1 / pad R: my[k] / mx[k] = mapped row / column
+// of kernel tap k for the thread's pixel (branch-free, computed once); any neighbour n is then two
+// register selects.
+template <int R>
+struct NbrMap {
+  static constexpr int K = 2 * R + 1;
+  int my[K], mx[K];
+  __device__ __forceinline__ void init(const KP& g, int py, int px) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      my[k] = map_index_bf(py + k - R, g.H, g.mode);
+      mx[k] = map_index_bf(px + k - R, g.W, g.mode);
     }
   }
-  return v;
+  __device__ __forceinline__ int get(const KP& g, int n, int& qy, int& qx) const {
+    const int tp = n + (n >= (K * K) / 2 ? 1 : 0);
+    const int ky = tp / K, kx = tp - ky * K;  // K is a compile-time constant
+    qy = my[0];
+    qx = mx[0];
+#pragma unroll
+    for (int k = 1; k < K; ++k) {
+      qy = ky == k ? my[k] : qy;
+      qx = kx == k ? mx[k] : qx;
+    }
+    return (qy < 0 || qx < 0) ? -1 : qy * g.W + qx;
+  }
+};
+
+// LDS slot of pixel p inside a channel-quad row (row stride Pp = P rounded up to 4 slots): pixels are
+// rotated inside their group of four by (p >> 3) & 3.  The NCHW staging writes a 4-pixel block per
+// lane, i.e. lanes 64 B apart; unrotated that is a 4-way bank conflict on every ds_write_b128
+// (measured: half of all LDS cycles); rotated, each 8-lane write group covers all 32 banks.  Reads
+// of consecutive pixels stay conflict-free (a permutation inside each 64-byte group).
+__device__ __forceinline__ int swz(int p) { return (p & ~3) | (((p & 3) + (p >> 3)) & 3); }
+
+// exact i / d for 0 <= i, quotient < 2048 (d >= 1): float multiply instead of the ~20-instruction
+// integer division sequence
+__device__ __forceinline__ int fast_div(int i, float inv_d) { return (int)(((float)i + 0.5f) * inv_d); }
+
+// `x` is the (wave-uniform) image base, `e` a 32-bit element offset: hipcc then emits the
+// SGPR-base + VGPR-offset form of global_load with no 64-bit vector address arithmetic.
+template <bool BF>
+__device__ __forceinline__ float4 load_px4(const void* x, int e) {  // 4 consecutive elements
+  if constexpr (!BF) {
+    return *(const float4*)((const float*)x + e);  // 4-byte aligned is enough for global_load_dwordx4
+  } else {
+    uint2 u = *(const uint2*)((const uint16_t*)x + e);
+    float4 v;
+    v.x = __uint_as_float(u.x << 16);
+    v.y = __uint_as_float(u.x & 0xffff0000u);
+    v.z = __uint_as_float(u.y << 16);
+    v.w = __uint_as_float(u.y & 0xffff0000u);
+    return v;
+  }
+}
+template <bool BF>
+__device__ __forceinline__ float load_1(const void* x, int e) {
+  if constexpr (!BF)
+    return ((const float*)x)[e];
+  else
+    return bf16_to_f32(((const uint16_t*)x)[e]);
 }
 
-__device__ __forceinline__ void st4(void* x, const KP& g, bool nhwc, long long img, int c, int p, float4 v) {
-  if (g.dtype == NFP_F32) {
-    float* s = (float*)x + img;
-    if (nhwc) {
-      *(float4*)(s + (long long)p * g.C + c) = v;
+// Staged registers of one chunk.  Every load is unconditional (indices clamped onto valid slots);
+// a runtime select around a load makes hipcc serialise the loads behind vmcnt(0) waits.
+template <bool NHWC>
+struct Staged;
+template <>
+struct Staged<false> {
+  float4 blk[kRB][4];  // [round][channel j] = 4 consecutive pixels of channel 4cq+j
+  float4 tl[kRT];      // 4 channels of one tail pixel
+};
+template <>
+struct Staged<true> {
+  float4 v[kRN];
+};
+
+// NCHW issue order: tail pixels first, then block round 0, then block round 1 — data returns in
+// issue order, so the slab can be committed and consumed round by round while later loads fly.
+template <bool BF>
+__device__ __forceinline__ void stage_load(Staged<false>& s, const void* x, const KP& g, int c0, int ncq, int t,
+                                           int T) {
+  // straight-line: no branch may wrap a load (hipcc would wait for the loads inside it before
+  // issuing the next ones).  P >= 4 is guaranteed by the dispatcher; with P % 4 == 0 the tail
+  // loads degenerate to clamped duplicates of the last pixel and nothing is stored from them.
+  const int P = g.P, NQ = P >> 2, PT = P & 3;
+  const int nblk = ncq * NQ, ntl = ncq * PT;
+  const float invq = g.invNQ, invt = g.invPT;
+#pragma unroll
+  for (int r = 0; r < kRT; ++r) {
+    const int i = max(min(t + r * T, ntl - 1), 0);
+    const int cq = fast_div(i, invt), pt = i - cq * max(PT, 1);
+    const int e = (c0 + 4 * cq) * P + min(4 * NQ + pt, P - 1);
+    s.tl[r].x = load_1<BF>(x, e);
+    s.tl[r].y = load_1<BF>(x, e + P);
+    s.tl[r].z = load_1<BF>(x, e + 2 * P);
+    s.tl[r].w = load_1<BF>(x, e + 3 * P);
+  }
+#pragma unroll
+  for (int r = 0; r < kRB; ++r) {
+    const int i = min(t + r * T, nblk - 1);
+    const int cq = fast_div(i, invq), pq = i - cq * NQ;
+    const int e = (c0 + 4 * cq) * P + 4 * pq;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s.blk[r][j] = load_px4<BF>(x, e + j * P);
+  }
+}
+// commit the tail slots and block round `r0..r1-1`
+template <bool BF>
+__device__ __forceinline__ void stage_store(const Staged<false>& s, float4* slab, const KP& g, int ncq, int t, int T,
+                                            bool tails, int r0, int r1) {
+  const int P = g.P, NQ = P >> 2, PT = P & 3, Pp = (P + 3) & ~3;
+  const int nblk = ncq * NQ, ntl = ncq * PT;
+  const float invq = g.invNQ, invt = g.invPT;
+  if (tails) {
+#pragma unroll
+    for (int r = 0; r < kRT; ++r) {
+      const int i = t + r * T;
+      if (i < ntl) {
+        const int cq = fast_div(i, invt), pt = i - cq * PT;
+        slab[cq * Pp + swz(4 * NQ + pt)] = s.tl[r];
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < kRB; ++r) {
+    const int i = t + r * T;
+    if (r >= r0 && r < r1 && i < nblk) {
+      const int cq = fast_div(i, invq), pq = i - cq * NQ;
+      float4* d = slab + cq * Pp + 4 * pq;
+      const int rot = (pq >> 1) & 3;  // = swz() of the block's four pixels
+      d[rot] = make_float4(s.blk[r][0].x, s.blk[r][1].x, s.blk[r][2].x, s.blk[r][3].x);
+      d[(rot + 1) & 3] = make_float4(s.blk[r][0].y, s.blk[r][1].y, s.blk[r][2].y, s.blk[r][3].y);
+      d[(rot + 2) & 3] = make_float4(s.blk[r][0].z, s.blk[r][1].z, s.blk[r][2].z, s.blk[r][3].z);
+      d[(rot + 3) & 3] = make_float4(s.blk[r][0].w, s.blk[r][1].w, s.blk[r][2].w, s.blk[r][3].w);
+    }
+  }
+}
+
+// channels-last: slot (cq, p) is 4 contiguous channels; thread (p, gl) takes cq = gl, gl+G, ...
+template <bool BF>
+__device__ __forceinline__ void stage_load(Staged<true>& s, const void* x, const KP& g, int c0, int ncq, int p,
+                                           int gl, bool active) {
+  const int g0 = active ? gl : 0;
+  const int last = g0 < ncq ? g0 + ((ncq - 1 - g0) / g.G) * g.G : 0;
+#pragma unroll
+  for (int k = 0; k < kRN; ++k) {
+    const int cq = min(g0 + k * g.G, last);
+    s.v[k] = load_px4<BF>(x, p * g.C + c0 + 4 * cq);
+  }
+}
+__device__ __forceinline__ void stage_store(const Staged<true>& s, float4* slab, const KP& g, int ncq, int p, int gl,
+                                            bool active) {
+#pragma unroll
+  for (int k = 0; k < kRN; ++k) {
+    const int cq = gl + k * g.G;
+    if (active && cq < ncq) slab[cq * ((g.P + 3) & ~3) + swz(p)] = s.v[k];
+  }
+}
+
+template <bool BF, bool NHWC>
+__device__ __forceinline__ void stage_issue(Staged<NHWC>& s, const void* x, const KP& g, int c0, int ncq, int t,
+                                            int T, int p, int gl, bool active) {
+  if constexpr (NHWC)
+    stage_load<BF>(s, x, g, c0, ncq, p, gl, active);
+  else
+    stage_load<BF>(s, x, g, c0, ncq, t, T);
+}
+// Commit stage `part` of kParts (NCHW: part r = block round r, tails with part 0; channels-last has
+// a single effective part).  Returns the number of channel quads complete after it.
+template <bool BF, bool NHWC>
+__device__ __forceinline__ int stage_commit(const Staged<NHWC>& s, float4* slab, const KP& g, int ncq, int t, int T,
+                                            int p, int gl, bool active, int part) {
+  if constexpr (NHWC) {
+    if (part == 0) stage_store(s, slab, g, ncq, p, gl, active);
+    return ncq;
+  } else {
+    // part r commits block round r (plus the tails with part 0); quads whose every block has been
+    // committed so far are complete
+    stage_store<BF>(s, slab, g, ncq, t, T, part == 0, part, part + 1);
+    return part + 1 >= kRB ? ncq : min(ncq, ((part + 1) * T) / (g.P >> 2));
+  }
+}
+
+// grad_x slot (4 channels of pixel p); `x` is the image base, offsets are 32-bit
+template <bool BF, bool NHWC>
+__device__ __forceinline__ void st4(void* x, const KP& g, int c, int p, float4 v) {
+  if constexpr (!BF) {
+    float* s = (float*)x;
+    if constexpr (NHWC) {
+      *(float4*)(s + (p * g.C + c)) = v;
     } else {
-      float* q = s + (long long)c * g.P + p;
-      q[0] = v.x;
-      q[g.P] = v.y;
-      q[2 * g.P] = v.z;
-      q[3 * g.P] = v.w;
+      const int e = c * g.P + p;
+      s[e] = v.x;
+      s[e + g.P] = v.y;
+      s[e + 2 * g.P] = v.z;
+      s[e + 3 * g.P] = v.w;
     }
   } else {
-    uint16_t* s = (uint16_t*)x + img;
-    if (nhwc) {
+    uint16_t* s = (uint16_t*)x;
+    if constexpr (NHWC) {
       uint2 u;
       u.x = (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16);
       u.y = (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16);
-      *(uint2*)(s + (long long)p * g.C + c) = u;
+      *(uint2*)(s + (p * g.C + c)) = u;
     } else {
-      uint16_t* q = s + (long long)c * g.P + p;
-      q[0] = f32_to_bf16(v.x);
-      q[g.P] = f32_to_bf16(v.y);
-      q[2 * g.P] = f32_to_bf16(v.z);
-      q[3 * g.P] = f32_to_bf16(v.w);
+      const int e = c * g.P + p;
+      s[e] = f32_to_bf16(v.x);
+      s[e + g.P] = f32_to_bf16(v.y);
+      s[e + 2 * g.P] = f32_to_bf16(v.z);
+      s[e + 3 * g.P] = f32_to_bf16(v.w);
     }
   }
 }
 
-// pair sum of two distinct in-image pixels from the half-stencil table Tt[(NF+1)][P]
-template <int R>
-__device__ __forceinline__ float pair_lookup(const float* Tt, const KP& g, int p, int q) {
-  int py = p / g.W, px = p - py * g.W, qy = q / g.W, qx = q - qy * g.W;
-  int dy = qy - py, dx = qx - px;
-  if (dy > 0 || (dy == 0 && dx > 0)) return Tt[fidx<R>(dy, dx) * g.P + p];
-  return Tt[fidx<R>(-dy, -dx) * g.P + q];
+// 1 / max(sqrt(n2), eps) = min(rsqrt(n2), 1/eps): one v_rsq_f32 (1 ulp) instead of an IEEE sqrt and
+// an IEEE divide (~25 instructions on the finalize critical path); rsqrt(0) = inf -> 1/eps.
+__device__ __forceinline__ float inv_norm(float n2, float inv_eps) {
+  return fminf(__builtin_amdgcn_rsqf(n2), inv_eps);
 }
 
 // ---- forward --------------------------------------------------------------------------------
-template <int R, int M>
+template <int R, int M, bool BF, bool NHWC>
 __global__ void __launch_bounds__(kFwdThreads) fwd_fast(const KP g, const void* __restrict__ x, void* __restrict__ out,
-                                                 float* __restrict__ saved) {
+                                                        float* __restrict__ saved) {
   constexpr int N = Win<R>::N, NF = Win<R>::NF;
   extern __shared__ __attribute__((aligned(16))) float4 lds4[];
   float4* slab = lds4;
   const int P = g.P;
   const int b = blockIdx.x, t = threadIdx.x, T = blockDim.x;
-  const int p = t % P, gl = t / P;
+  const int gl = fast_div(t, g.invP), p = t - gl * P;
+  const int py = fast_div(p, g.invW), px = p - py * g.W;
   const bool active = gl < g.G;
-  const bool nhwc = !g.contig;
-  const long long img = (long long)b * g.sB;
+  constexpr int ES = BF ? 2 : 4;
+  const void* xb = (const char*)x + (long long)b * g.sB * ES;  // wave-uniform image base
+
+  NFP_STAMP_INIT();
+  NFP_STAMP(0);
+  NFP_STAMP(6);
+  Staged<NHWC> st;
+#if NFP_ABLATE & 4
+  __builtin_memset(&st, 0, sizeof(st));
+#else
+  stage_issue<BF, NHWC>(st, xb, g, 0, min(g.Cc, g.C) >> 2, t, T, p, gl, active);
+#endif
+  __builtin_amdgcn_sched_barrier(0);
+  NFP_STAMP(1);
 
   int off[NF];
-  {
-    const int py = p / g.W, px = p - py * g.W;
 #pragma unroll
-    for (int d = 0; d < NF; ++d) {
-      int dy, dx;
-      fdir<R>(d, dy, dx);
-      bool ok = (px + dx >= 0) && (px + dx < g.W) && (py + dy < g.H);
-      off[d] = ok ? dy * g.W + dx : 0;  // invalid pairs read the own slot: finite junk, never looked up
-    }
+  for (int d = 0; d < NF; ++d) {
+    int dy, dx;
+    fdir<R>(d, dy, dx);
+    bool ok = (px + dx >= 0) && (px + dx < g.W) && (py + dy < g.H);
+    off[d] = ok ? swz(p + dy * g.W + dx) - swz(p) : 0;  // invalid pairs read the own slot: finite junk, never used
   }
   float acc[NF];
 #pragma unroll
   for (int d = 0; d < NF; ++d) acc[d] = 0.f;
   float nrm = 0.f;
+  const int Pp = (P + 3) & ~3, sp = swz(p);
 
   for (int c0 = 0; c0 < g.C; c0 += g.Cc) {
     const int ncq = min(g.Cc, g.C - c0) >> 2;
-    float4 v[kMaxK];
-#pragma unroll
-    for (int k = 0; k < kMaxK; ++k) {
-      int cq = gl + k * g.G;
-      if (active && cq < ncq) v[k] = ld4(x, g, nhwc, img, c0 + 4 * cq, p);
+    if (c0 > 0) {
+      __syncthreads();  // previous chunk fully consumed
+      stage_issue<BF, NHWC>(st, xb, g, c0, ncq, t, T, p, gl, active);
     }
-    if (c0 > 0) __syncthreads();  // previous chunk fully consumed
+    int done = 0;
 #pragma unroll
-    for (int k = 0; k < kMaxK; ++k) {
-      int cq = gl + k * g.G;
-      if (active && cq < ncq) slab[cq * P + p] = v[k];
-    }
-    __syncthreads();
-    if (active) {
-      for (int cq = gl; cq < ncq; cq += g.G) {
-        const float4* row = slab + cq * P + p;
-        const float4 a = row[0];
-        nrm = fmaf(a.x, a.x, fmaf(a.y, a.y, fmaf(a.z, a.z, fmaf(a.w, a.w, nrm))));
+    for (int part = 0; part < kRB; ++part) {
+#if NFP_ABLATE & 2
+      const int upto = part + 1 >= kRB ? ncq : min(ncq, ((part + 1) * T) / (g.P >> 2));
+      if constexpr (!NHWC) asm volatile("" ::"v"(st.blk[0][0].x), "v"(st.blk[kRB - 1][3].w), "v"(st.tl[0].x));
+#else
+      const int upto = stage_commit<BF, NHWC>(st, slab, g, ncq, t, T, p, gl, active, part);
+#endif
+      if (upto == done) continue;  // uniform: nothing new became complete
+      __syncthreads();
+      if (part == 0) NFP_STAMP(2);
+      if (active && !(NFP_ABLATE & 1)) {
+        // this thread's quads gl, gl+G, ... inside [done, upto)
+        int cq = gl + ((max(done - gl, 0) + g.G - 1) / g.G) * g.G;
+        for (; cq < upto; cq += g.G) {
+          const float4* row = slab + cq * Pp + sp;
+          const float4 a = row[0];
+          nrm = fmaf(a.x, a.x, fmaf(a.y, a.y, fmaf(a.z, a.z, fmaf(a.w, a.w, nrm))));
 #pragma unroll
-        for (int d = 0; d < NF; ++d) {
-          const float4 q = row[off[d]];
-          if (M == NFP_COSINE) {
-            acc[d] = fmaf(a.x, q.x, fmaf(a.y, q.y, fmaf(a.z, q.z, fmaf(a.w, q.w, acc[d]))));
-          } else {
-            float e0 = a.x - q.x, e1 = a.y - q.y, e2 = a.z - q.z, e3 = a.w - q.w;
-            acc[d] = fmaf(e0, e0, fmaf(e1, e1, fmaf(e2, e2, fmaf(e3, e3, acc[d]))));
+          for (int d = 0; d < NF; ++d) {
+            const float4 q = row[off[d]];
+            if (M == NFP_COSINE) {
+              acc[d] = fmaf(a.x, q.x, fmaf(a.y, q.y, fmaf(a.z, q.z, fmaf(a.w, q.w, acc[d]))));
+            } else {
+              float e0 = a.x - q.x, e1 = a.y - q.y, e2 = a.z - q.z, e3 = a.w - q.w;
+              acc[d] = fmaf(e0, e0, fmaf(e1, e1, fmaf(e2, e2, fmaf(e3, e3, acc[d]))));
+            }
           }
         }
       }
+      done = upto;
     }
   }
-  // cross-lane (channel group) reduction through LDS, fixed order
+#if NFP_ABLATE & 8
+  if (active) stx(out, ((long long)b * N) * P + p + gl * P, acc[0] + acc[NF - 1] + nrm, NFP_F32);
+  return;
+#endif
+  // channel-group reduction through LDS, fixed order
   __syncthreads();
-  float* red = (float*)lds4;                 // [G][NF+1][P]
-  float* Tt = red + g.G * (NF + 1) * P;      // [NF+1][P]
+  NFP_STAMP(3);
+  float* red = (float*)lds4;             // [G][NF+1][P]
+  float* Tt = red + g.G * (NF + 1) * P;  // [NF+1][P]
   if (active) {
 #pragma unroll
     for (int d = 0; d < NF; ++d) red[(gl * (NF + 1) + d) * P + p] = acc[d];
@@ -205,162 +384,231 @@ __global__ void __launch_bounds__(kFwdThreads) fwd_fast(const KP g, const void* 
     Tt[i] = s;
   }
   __syncthreads();
+  NFP_STAMP(4);
+  // outputs: thread (p, n = gl, gl+G, ...); stride-1 "same" geometry => output pixel == centre pixel
   const float* n2 = Tt + NF * P;
-  for (int i = t; i < N * P; i += T) {
-    const int n = i / P, pp = i - n * P;
-    const int q = nbr_pixel(g, pp, n);
-    float v;
-    if (M == NFP_COSINE) {
-      float s = 0.f;
-      if (q >= 0) {
-        float ip = 1.f / fmaxf(sqrtf(n2[pp]), g.eps), iq = 1.f / fmaxf(sqrtf(n2[q]), g.eps);
-        float dot = (q == pp) ? n2[pp] : pair_lookup<R>(Tt, g, pp, q);
-        s = dot * ip * iq;
+  if (active) {
+    NbrMap<R> nm;
+    nm.init(g, py, px);
+    void* ob = (char*)out + (long long)b * N * P * ES;
+    const float n2p = n2[p];
+    const float ip = inv_norm(n2p, g.inv_eps);
+    for (int n = gl; n < N; n += g.G) {
+      int qy, qx;
+      const int q = nm.get(g, n, qy, qx);
+      const int qc = max(q, 0);
+      const int dy = qy - py, dx = qx - px;
+      const bool fwd = dy > 0 || (dy == 0 && dx > 0);
+      // distinct in-image pair: the half-stencil table entry (index clamped when unused)
+      const int fi = fwd ? fidx<R>(dy, dx) : fidx<R>(-dy, -dx);
+      const bool pair_ok = q >= 0 && q != p;
+      const float pairv = Tt[(pair_ok ? fi : 0) * P + (fwd ? p : qc)];
+      const float n2q = n2[qc];
+      float v;
+      if (M == NFP_COSINE) {
+        const float s = q < 0 ? 0.f : (q == p ? n2p : pairv) * ip * inv_norm(n2q, g.inv_eps);
+        v = g.similarity ? s : 1.f - s;
+      } else {
+        float d2;
+        if (g.diff)
+          d2 = q < 0 ? n2p : (q == p ? 0.f : pairv);
+        else
+          d2 = q < 0 ? 0.f : n2q;  // 'Norm' quirk (nfp.py:74 vs 85): |neighbour|
+        const float dd = __builtin_amdgcn_sqrtf(d2);
+        v = g.similarity ? -dd : dd;
       }
-      v = g.similarity ? s : 1.f - s;
-    } else {
-      float d2;
-      if (g.diff)
-        d2 = q < 0 ? n2[pp] : (q == pp ? 0.f : pair_lookup<R>(Tt, g, pp, q));
-      else
-        d2 = q < 0 ? 0.f : n2[q];  // 'Norm' quirk (nfp.py:74 vs 85): |neighbour|
-      float dd = sqrtf(d2);
-      v = g.similarity ? -dd : dd;
+      stx(ob, n * P + p, v, BF ? NFP_BF16 : NFP_F32);
     }
-    stx(out, ((long long)b * N + n) * P + pp, v, g.dtype);
+    if (M == NFP_COSINE && saved != nullptr && gl == 0) saved[(long long)b * P + p] = __builtin_amdgcn_sqrtf(n2p);
   }
-  if (M == NFP_COSINE && saved != nullptr)
-    for (int i = t; i < P; i += T) saved[(long long)b * P + i] = sqrtf(n2[i]);
+  NFP_STAMP(5);
 }
 
 // ---- backward -------------------------------------------------------------------------------
-template <int R, int M>
-__global__ void __launch_bounds__(kBwdThreads) bwd_fast(const KP g, const void* __restrict__ x, const void* __restrict__ go,
-                                                 const void* __restrict__ out, const float* __restrict__ saved,
-                                                 void* __restrict__ gx) {
+template <int R, int M, bool BF, bool NHWC>
+__global__ void __launch_bounds__(kBwdThreads) bwd_fast(const KP g, const void* __restrict__ x,
+                                                        const void* __restrict__ go, const void* __restrict__ out,
+                                                        const float* __restrict__ saved, void* __restrict__ gx) {
   constexpr int K = Win<R>::K, K2 = Win<R>::K2, N = Win<R>::N;
   extern __shared__ __attribute__((aligned(16))) float4 lds4[];
   const int P = g.P;
   // LDS: Wt (lives to the end) | union { x slab , coefficient tables (dead once Wt is built) }
-  float* Wt = (float*)lds4;                             // [P][K2] gathered weights
-  float4* slab = lds4 + ((P * K2 + 3) >> 2);            // [Cc/4][P]
-  float* CR = (float*)slab;                             // [P][N] cross coefficient of pair (p, n)
-  float* SP = CR + P * N;                               // [P][N] self coefficient on the centre
-  float* SQ = SP + P * N;                               // [P][N] self coefficient on the neighbour
-  float* Sq2 = SQ + P * N;                              // [P][K2] neighbour-role self terms per window slot
+  float* Wt = (float*)lds4;                    // [P][K2] gathered weights
+  float4* slab = lds4 + ((P * K2 + 3) >> 2);   // [Cc/4][P]
+  int* Qt = (int*)slab;                        // [P][N] neighbour pixel of (p, n), -1 = zero pad
+  float* CR = (float*)(Qt + P * N);            // [P][N] cross coefficient of pair (p, n)
+  float* SP = CR + P * N;                      // [P][N] self coefficient on the centre
+  float* SQ = SP + P * N;                      // [P][N] self coefficient on the neighbour
+  float* Sq2 = SQ + P * N;                     // [P][K2] neighbour-role self terms per window slot
   const int b = blockIdx.x, t = threadIdx.x, T = blockDim.x;
   const int cb0 = blockIdx.y * g.Cwg, cb1 = min(g.C, cb0 + g.Cwg);
-  const int p = t % P, gl = t / P;
+  const int gl = fast_div(t, g.invP), p = t - gl * P;
+  const int py = fast_div(p, g.invW), px = p - py * g.W;
   const bool active = gl < g.G;
-  const bool nhwc = !g.contig;
-  const long long img = (long long)b * g.sB;
+  constexpr int DT = BF ? NFP_BF16 : NFP_F32;
+  constexpr int ES = BF ? 2 : 4;
+  const void* xb = (const char*)x + (long long)b * g.sB * ES;   // wave-uniform image bases
+  void* gxb = (char*)gx + (long long)b * g.sB * ES;
+  const void* gob = (const char*)go + (long long)b * N * P * ES;
+  const void* outb = (const char*)out + (long long)b * N * P * ES;
 
-  // x loads of the first chunk go out before the coefficient phase so they fly under it
-  float4 v[kMaxK];
-  {
-    const int ncq = min(g.Cc, cb1 - cb0) >> 2;
+  NFP_STAMP_INIT();
+  NFP_STAMP(0);
+  // A1: per-pair coefficients -> LDS tables.  Thread (p, n = gl, gl+G, ...), four n per round with
+  // their loads batched.  The first round's loads are issued BEFORE the x chunk and the x chunk
+  // before the first round's arithmetic: loads return in issue order, so the coefficient phase
+  // starts after one memory latency while x streams in underneath it.
+  NbrMap<R> nm;
+  nm.init(g, py, px);
+  struct A1 {
+    float gv[4], ov[4], nqv[4];
+    int qn[4];
+  } a1;
+  const float* svb = (M == NFP_COSINE) ? saved + (long long)b * P : nullptr;
+  const float np_ = (M == NFP_COSINE) ? svb[p] : 0.f;
+  auto a1_load = [&](int n0) {
 #pragma unroll
-    for (int k = 0; k < kMaxK; ++k) {
-      int cq = gl + k * g.G;
-      if (active && cq < ncq) v[k] = ld4(x, g, nhwc, img, cb0 + 4 * cq, p);
+    for (int u = 0; u < 4; ++u) {
+      const int n = min(n0 + u * g.G, N - 1);
+      int qy, qx;
+      a1.qn[u] = nm.get(g, n, qy, qx);
+      a1.gv[u] = ldx(gob, n * P + p, DT);
+      a1.ov[u] = ldx(outb, n * P + p, DT);
+      a1.nqv[u] = (M == NFP_COSINE) ? svb[max(a1.qn[u], 0)] : 0.f;
     }
-  }
-  // A1: per-pair coefficients
-  for (int i = t; i < P * N; i += T) {
-    const int pp = i / N, n = i - pp * N;
-    const long long oi = ((long long)b * N + n) * P + pp;
-    const float gv = ldx(go, oi, g.dtype), ov = ldx(out, oi, g.dtype);
-    const int q = nbr_pixel(g, pp, n);
-    float cr = 0.f, sp = 0.f, sq = 0.f;
-    if (M == NFP_COSINE) {
-      if (q >= 0) {
-        const float np_ = saved[(long long)b * P + pp], nq = saved[(long long)b * P + q];
-        const float s = g.similarity ? ov : 1.f - ov;
-        const float sg = g.similarity ? gv : -gv;
-        const float ip = 1.f / fmaxf(np_, g.eps), iq = 1.f / fmaxf(nq, g.eps);
-        cr = sg * ip * iq;
-        sp = np_ > 0.f ? -sg * s * ip / np_ : 0.f;
-        sq = nq > 0.f ? -sg * s * iq / nq : 0.f;
-      }
-    } else {
-      const float d = fabsf(ov);
-      const float c = d == 0.f ? 0.f : (g.similarity ? -gv : gv) / d;
-      if (g.diff) {
-        sp = c;
-        if (q >= 0) {
-          cr = -c;
-          sq = c;
+  };
+  auto a1_math = [&](int n0) {
+    // pin the loaded values: hipcc otherwise re-issues ("rematerialises") some of these loads here and
+    // waits vmcnt(0) for them, which drains the x chunk that is still streaming in
+#pragma unroll
+    for (int u = 0; u < 4; ++u) asm volatile("" : "+v"(a1.gv[u]), "+v"(a1.ov[u]), "+v"(a1.nqv[u]));
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int n = n0 + u * g.G;
+      if (active && n < N) {
+        const int q = a1.qn[u];
+        float cr = 0.f, sp = 0.f, sq = 0.f;
+        if (M == NFP_COSINE) {
+          // 1/max(|.|,eps) and 1/|.| by v_rcp_f32 (1 ulp); 0 where the norm is 0 (torch's subgradient)
+          const float s = g.similarity ? a1.ov[u] : 1.f - a1.ov[u];
+          const float sg = g.similarity ? a1.gv[u] : -a1.gv[u];
+          const float nq = a1.nqv[u];
+          const float ip = __builtin_amdgcn_rcpf(fmaxf(np_, g.eps)), iq = __builtin_amdgcn_rcpf(fmaxf(nq, g.eps));
+          const float rp = np_ > 0.f ? __builtin_amdgcn_rcpf(np_) : 0.f, rq = nq > 0.f ? __builtin_amdgcn_rcpf(nq) : 0.f;
+          const float t0 = sg * ip;
+          cr = q >= 0 ? t0 * iq : 0.f;
+          sp = q >= 0 ? -t0 * s * rp : 0.f;
+          sq = q >= 0 ? -sg * s * iq * rq : 0.f;
+        } else {
+          const float d = fabsf(a1.ov[u]);
+          const float c = d == 0.f ? 0.f : (g.similarity ? -a1.gv[u] : a1.gv[u]) * __builtin_amdgcn_rcpf(d);
+          if (g.diff) {
+            sp = c;
+            cr = q >= 0 ? -c : 0.f;
+            sq = q >= 0 ? c : 0.f;
+          } else {
+            sq = q >= 0 ? c : 0.f;  // d|x_q| / dx_q only
+          }
         }
-      } else if (q >= 0) {
-        sq = c;  // d|x_q| / dx_q only
+        Qt[p * N + n] = q;
+        CR[p * N + n] = cr;
+        SP[p * N + n] = sp;
+        SQ[p * N + n] = sq;
       }
     }
-    CR[i] = cr;
-    SP[i] = sp;
-    SQ[i] = sq;
+  };
+  a1_load(gl);
+  __builtin_amdgcn_sched_barrier(0);  // keep these (small, needed first) loads ahead of the x chunk
+  Staged<NHWC> st;
+  stage_issue<BF, NHWC>(st, xb, g, cb0, min(g.Cc, cb1 - cb0) >> 2, t, T, p, gl, active);
+  // nothing that consumes a loaded value may be scheduled above this line (hipcc otherwise hoists
+  // e.g. rcp(|x_p|) into the load sequence and stalls the remaining loads behind a vmcnt wait)
+  __builtin_amdgcn_sched_barrier(0);
+  NFP_STAMP(1);
+  a1_math(gl);
+  for (int n0 = gl + 4 * g.G; n0 < N; n0 += 4 * g.G) {
+    a1_load(n0);
+    a1_math(n0);
   }
   __syncthreads();
-  // A2: gather.  Entry (r, slot j) with t = r + delta_j in the image.
-  for (int i = t; i < P * K2; i += T) {
-    const int r = i / K2, j = i - r * K2;
-    const int ry = r / g.W, rx = r - ry * g.W;
-    const int ty = ry + j / K - R, tx = rx + j % K - R;
-    float w = 0.f, s2 = 0.f;
-    if (ty >= 0 && ty < g.H && tx >= 0 && tx < g.W) {
-      const int tt = ty * g.W + tx;
-      for (int n = 0; n < N; ++n)  // r as centre, tt as its neighbour n
-        if (nbr_pixel(g, r, n) == tt) w += CR[r * N + n];
-      for (int n = 0; n < N; ++n)  // tt as centre, r as its neighbour n
-        if (nbr_pixel(g, tt, n) == r) {
-          w += CR[tt * N + n];
-          s2 += SQ[tt * N + n];
+  NFP_STAMP(2);
+  // A2: gather.  Thread (r = p, slot j = gl, gl+G, ...), t = r + delta_j if inside the image.
+  if (active) {
+    for (int j = gl; j < K2; j += g.G) {
+      const int jy = j / K, jx = j - jy * K;
+      const int ty = py + jy - R, tx = px + jx - R;
+      float w = 0.f, s2 = 0.f;
+      if (ty >= 0 && ty < g.H && tx >= 0 && tx < g.W) {
+        const int tt = ty * g.W + tx;
+        const int4* qa = (const int4*)(Qt + p * N);
+        const float4* ca = (const float4*)(CR + p * N);
+        const int4* qb = (const int4*)(Qt + tt * N);
+        const float4* cb = (const float4*)(CR + tt * N);
+        const float4* sb = (const float4*)(SQ + tt * N);
+#pragma unroll
+        for (int m = 0; m < N / 4; ++m) {  // r as centre, tt as its neighbour
+          const int4 qq = qa[m];
+          const float4 cc = ca[m];
+          w += (qq.x == tt ? cc.x : 0.f) + (qq.y == tt ? cc.y : 0.f) + (qq.z == tt ? cc.z : 0.f) +
+               (qq.w == tt ? cc.w : 0.f);
         }
-      if (tt == r)
-        for (int n = 0; n < N; ++n) w += SP[r * N + n];
+#pragma unroll
+        for (int m = 0; m < N / 4; ++m) {  // tt as centre, r as its neighbour
+          const int4 qq = qb[m];
+          const float4 cc = cb[m];
+          const float4 ss = sb[m];
+          w += (qq.x == p ? cc.x : 0.f) + (qq.y == p ? cc.y : 0.f) + (qq.z == p ? cc.z : 0.f) +
+               (qq.w == p ? cc.w : 0.f);
+          s2 += (qq.x == p ? ss.x : 0.f) + (qq.y == p ? ss.y : 0.f) + (qq.z == p ? ss.z : 0.f) +
+                (qq.w == p ? ss.w : 0.f);
+        }
+        if (tt == p) {
+          const float4* sa = (const float4*)(SP + p * N);
+#pragma unroll
+          for (int m = 0; m < N / 4; ++m) {
+            const float4 ss = sa[m];
+            w += (ss.x + ss.y) + (ss.z + ss.w);
+          }
+        }
+      }
+      Wt[p * K2 + j] = w;
+      Sq2[p * K2 + j] = s2;
     }
-    Wt[i] = w;
-    Sq2[i] = s2;
   }
   __syncthreads();
+  NFP_STAMP(3);
   // A3: fold the neighbour-role self terms into the diagonal, fixed order
-  for (int r = t; r < P; r += T) {
-    float s = Wt[r * K2 + K2 / 2];
-    for (int j = 0; j < K2; ++j) s += Sq2[r * K2 + j];
-    Wt[r * K2 + K2 / 2] = s;
+  if (gl == 0) {
+    float s = Wt[p * K2 + K2 / 2];
+#pragma unroll
+    for (int j = 0; j < K2; ++j) s += Sq2[p * K2 + j];
+    Wt[p * K2 + K2 / 2] = s;
   }
   __syncthreads();
+  NFP_STAMP(4);
   float w[K2];
   int off[K2];
-  {
-    const int py = p / g.W, px = p - py * g.W;
 #pragma unroll
-    for (int j = 0; j < K2; ++j) {
-      const int dy = j / K - R, dx = j % K - R;
-      const bool ok = py + dy >= 0 && py + dy < g.H && px + dx >= 0 && px + dx < g.W;
-      off[j] = ok ? dy * g.W + dx : 0;
-      w[j] = ok ? Wt[p * K2 + j] : 0.f;
-    }
+  for (int j = 0; j < K2; ++j) {
+    const int dy = j / K - R, dx = j % K - R;
+    const bool ok = py + dy >= 0 && py + dy < g.H && px + dx >= 0 && px + dx < g.W;
+    off[j] = ok ? swz(p + dy * g.W + dx) - swz(p) : 0;
+    w[j] = ok ? Wt[p * K2 + j] : 0.f;
   }
   // B: one pass over the channel block
   for (int c0 = cb0; c0 < cb1; c0 += g.Cc) {
     const int ncq = min(g.Cc, cb1 - c0) >> 2;
     if (c0 > cb0) {
       __syncthreads();
-#pragma unroll
-      for (int k = 0; k < kMaxK; ++k) {
-        int cq = gl + k * g.G;
-        if (active && cq < ncq) v[k] = ld4(x, g, nhwc, img, c0 + 4 * cq, p);
-      }
+      stage_issue<BF, NHWC>(st, xb, g, c0, ncq, t, T, p, gl, active);
     }
 #pragma unroll
-    for (int k = 0; k < kMaxK; ++k) {
-      int cq = gl + k * g.G;
-      if (active && cq < ncq) slab[cq * P + p] = v[k];
-    }
+    for (int part = 0; part < kRB; ++part) stage_commit<BF, NHWC>(st, slab, g, ncq, t, T, p, gl, active, part);
     __syncthreads();
+    NFP_STAMP(5);
     if (active) {
       for (int cq = gl; cq < ncq; cq += g.G) {
-        const float4* row = slab + cq * P + p;
+        const float4* row = slab + cq * ((P + 3) & ~3) + swz(p);
         float4 r4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int j = 0; j < K2; ++j) {
@@ -370,10 +618,11 @@ __global__ void __launch_bounds__(kBwdThreads) bwd_fast(const KP g, const void* 
           r4.z = fmaf(w[j], q.z, r4.z);
           r4.w = fmaf(w[j], q.w, r4.w);
         }
-        st4(gx, g, nhwc, img, c0 + 4 * cq, p, r4);
+        st4<BF, NHWC>(gxb, g, c0 + 4 * cq, p, r4);
       }
     }
   }
+  NFP_STAMP(6);
 }
 
 }  // namespace nfp

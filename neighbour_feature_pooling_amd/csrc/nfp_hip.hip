@@ -74,6 +74,11 @@ int make_kp(const nfp_desc* d, KP* g) {
   g->p = d->p; g->eps = d->eps; g->q_scs = d->q_scs;
   g->sB = d->sxB; g->sC = d->sxC; g->sH = d->sxH; g->sW = d->sxW;
   g->contig = (d->sxW == 1 && d->sxH == d->W && d->sxC == (int64_t)d->H * d->W) ? 1 : 0;
+  g->invP = 1.0f / (float)g->P;
+  g->invW = 1.0f / (float)g->W;
+  g->invNQ = 1.0f / (float)((g->P >> 2) > 0 ? (g->P >> 2) : 1);
+  g->invPT = 1.0f / (float)((g->P & 3) > 0 ? (g->P & 3) : 1);
+  g->inv_eps = 1.0f / g->eps;
   if ((int64_t)g->P * 4 + 64 > kLdsMax)
     return fail(NFP_E_UNSUPPORTED, "feature map %dx%d does not fit one LDS channel slab", d->H, d->W);
   return NFP_OK;
@@ -160,7 +165,7 @@ bool fast_ok(const KP& g, const void* x, const void* gx) {
   if (force_generic()) return false;
   if (g.stride != 1 || g.dil != 1 || g.pad != g.R || g.mode == NFP_PAD_CIRCULAR) return false;
   if (g.R != 1 && g.R != 2) return false;
-  if ((g.C & 3) || g.P > kBwdThreads) return false;
+  if ((g.C & 3) || g.P > kBwdThreads || g.P < 4) return false;
   if (!(g.measure == NFP_COSINE || (g.measure == NFP_NORM && g.p == 2.f))) return false;
   const bool nhwc = g.sC == 1 && g.sW == g.C && g.sH == (long long)g.W * g.C;
   if (!g.contig && !nhwc) return false;
@@ -172,33 +177,64 @@ bool fast_ok(const KP& g, const void* x, const void* gx) {
 }
 
 int round4(int v) { return (v + 3) & ~3; }
+// fewest groups (<= gmax) that still finish ncq channel quads in ceil(ncq/gmax) rounds
+int even_groups(int ncq, int gmax) {
+  int rounds = (ncq + gmax - 1) / gmax;
+  return (ncq + rounds - 1) / rounds;
+}
 
-template <int R, int M>
-int launch_fwd_fast(KP g, const void* x, void* out, float* saved, hipStream_t st) {
+// channels per LDS chunk: bounded by the slab budget and by what one staging round-set can carry
+int chunk_channels(const KP& g, int total, int T, int G, bool nhwc, int budget) {
+  int ncq = budget / (((g.P + 3) & ~3) * 16);
+  if (nhwc) {
+    if (ncq > kRN * G) ncq = kRN * G;
+  } else {
+    const int NQ = g.P >> 2, PT = g.P & 3;
+    if (NQ > 0 && ncq > (kRB * T) / NQ) ncq = (kRB * T) / NQ;
+    if (PT > 0 && ncq > (kRT * T) / PT) ncq = (kRT * T) / PT;
+  }
+  if (ncq > 2047) ncq = 2047;  // fast_div quotient bound
+  if (ncq < 1) ncq = 1;
+  int cmax = 4 * ncq;
+  int nch = (total + cmax - 1) / cmax;
+  return round4((total + nch - 1) / nch);
+}
+
+template <int R, int M, bool BF, bool NHWC>
+int launch_fwd_fast_t(KP g, const void* x, void* out, float* saved, hipStream_t st) {
   constexpr int NF = Win<R>::NF;
   g.G = kFwdThreads / g.P;
   if (g.G < 1) g.G = 1;
   if (g.G > g.C / 4) g.G = g.C / 4;
-  int cmax = 4 * g.G * kMaxK;
-  int cbud = (kSlabBudgetFwd / (g.P * 16)) * 4;
-  if (cmax > cbud) cmax = cbud;
-  int nch = (g.C + cmax - 1) / cmax;
-  g.Cc = round4((g.C + nch - 1) / nch);
   int T = ((g.P * g.G + 63) / 64) * 64;
-  size_t slab = (size_t)(g.Cc / 4) * g.P * 16;
+  g.Cc = chunk_channels(g, g.C, T, g.G, NHWC, kSlabBudgetFwd);
+  g.G = even_groups(g.Cc / 4, g.G);
+  T = ((g.P * g.G + 63) / 64) * 64;
+  g.Cc = chunk_channels(g, g.C, T, g.G, NHWC, kSlabBudgetFwd);
+  size_t slab = (size_t)(g.Cc / 4) * ((g.P + 3) & ~3) * 16;
   size_t red = (size_t)(g.G + 1) * (NF + 1) * g.P * 4;
   size_t lds = slab > red ? slab : red;
   if (lds > (size_t)kLdsMax) return fail(NFP_E_UNSUPPORTED, "fwd_fast: LDS %zu", lds);
-  if (int rc = set_lds(fwd_fast<R, M>, lds)) return rc;
-  hipLaunchKernelGGL((fwd_fast<R, M>), dim3(g.B), dim3(T), lds, st, g, x, out, saved);
+  if (int rc = set_lds(fwd_fast<R, M, BF, NHWC>, lds)) return rc;
+  hipLaunchKernelGGL((fwd_fast<R, M, BF, NHWC>), dim3(g.B), dim3(T), lds, st, g, x, out, saved);
   g_launches++;
-  snprintf(g_variant, sizeof(g_variant), "fwd_fast<R%d,%s>", R, M == NFP_COSINE ? "cos" : "l2");
+  snprintf(g_variant, sizeof(g_variant), "fwd_fast<R%d,%s,%s,%s>", R, M == NFP_COSINE ? "cos" : "l2",
+           BF ? "bf16" : "f32", NHWC ? "nhwc" : "nchw");
   return hip_ok(hipGetLastError(), "launch fwd_fast");
 }
 
 template <int R, int M>
-int launch_bwd_fast(KP g, const void* x, const void* go, const void* out, const float* saved, void* gx,
-                    hipStream_t st) {
+int launch_fwd_fast(const KP& g, const void* x, void* out, float* saved, hipStream_t st) {
+  const bool bf = g.dtype == NFP_BF16, nhwc = !g.contig;
+  if (bf) return nhwc ? launch_fwd_fast_t<R, M, true, true>(g, x, out, saved, st)
+                      : launch_fwd_fast_t<R, M, true, false>(g, x, out, saved, st);
+  return nhwc ? launch_fwd_fast_t<R, M, false, true>(g, x, out, saved, st)
+              : launch_fwd_fast_t<R, M, false, false>(g, x, out, saved, st);
+}
+
+template <int R, int M, bool BF, bool NHWC>
+int launch_bwd_fast_t(KP g, const void* x, const void* go, const void* out, const float* saved, void* gx,
+                      hipStream_t st) {
   constexpr int N = Win<R>::N, K2 = Win<R>::K2;
   int S = (256 + g.B - 1) / g.B;  // channel blocks per image so that >= 256 workgroups exist
   if (S > g.C / 4) S = g.C / 4;
@@ -208,25 +244,42 @@ int launch_bwd_fast(KP g, const void* x, const void* go, const void* out, const 
   g.G = kBwdThreads / g.P;
   if (g.G < 1) g.G = 1;
   if (g.G > g.Cwg / 4) g.G = g.Cwg / 4;
+  int T = ((g.P * g.G + 63) / 64) * 64;
+  g.Cc = chunk_channels(g, g.Cwg, T, g.G, NHWC, kSlabBudgetBwd);
+  g.G = even_groups(g.Cc / 4, g.G);
+  T = ((g.P * g.G + 63) / 64) * 64;
+  g.Cc = chunk_channels(g, g.Cwg, T, g.G, NHWC, kSlabBudgetBwd);
   size_t wt = (size_t)g.P * K2 * 4;
-  size_t tables = (size_t)(3 * g.P * N + g.P * K2) * 4;
-  int cmax = 4 * g.G * kMaxK;
-  int cbud = (kSlabBudgetBwd / (g.P * 16)) * 4;
-  if (cmax > cbud) cmax = cbud;
-  int nch = (g.Cwg + cmax - 1) / cmax;
-  g.Cc = round4((g.Cwg + nch - 1) / nch);
-  size_t slab = (size_t)(g.Cc / 4) * g.P * 16;
+  size_t tables = (size_t)(4 * g.P * N + g.P * K2) * 4;
+  size_t slab = (size_t)(g.Cc / 4) * ((g.P + 3) & ~3) * 16;
   size_t lds = ((wt + 15) & ~(size_t)15) + (slab > tables ? slab : tables);
   if (lds > (size_t)kLdsMax) return fail(NFP_E_UNSUPPORTED, "bwd_fast: LDS %zu", lds);
-  int T = ((g.P * g.G + 63) / 64) * 64;
-  if (int rc = set_lds(bwd_fast<R, M>, lds)) return rc;
-  hipLaunchKernelGGL((bwd_fast<R, M>), dim3(g.B, S), dim3(T), lds, st, g, x, go, out, saved, gx);
+  if (int rc = set_lds(bwd_fast<R, M, BF, NHWC>, lds)) return rc;
+  hipLaunchKernelGGL((bwd_fast<R, M, BF, NHWC>), dim3(g.B, S), dim3(T), lds, st, g, x, go, out, saved, gx);
   g_launches++;
-  snprintf(g_variant, sizeof(g_variant), "bwd_fast<R%d,%s>", R, M == NFP_COSINE ? "cos" : "l2");
+  snprintf(g_variant, sizeof(g_variant), "bwd_fast<R%d,%s,%s,%s>", R, M == NFP_COSINE ? "cos" : "l2",
+           BF ? "bf16" : "f32", NHWC ? "nhwc" : "nchw");
   return hip_ok(hipGetLastError(), "launch bwd_fast");
 }
 
+template <int R, int M>
+int launch_bwd_fast(const KP& g, const void* x, const void* go, const void* out, const float* saved, void* gx,
+                    hipStream_t st) {
+  const bool bf = g.dtype == NFP_BF16, nhwc = !g.contig;
+  if (bf) return nhwc ? launch_bwd_fast_t<R, M, true, true>(g, x, go, out, saved, gx, st)
+                      : launch_bwd_fast_t<R, M, true, false>(g, x, go, out, saved, gx, st);
+  return nhwc ? launch_bwd_fast_t<R, M, false, true>(g, x, go, out, saved, gx, st)
+              : launch_bwd_fast_t<R, M, false, false>(g, x, go, out, saved, gx, st);
+}
+
 }  // namespace
+
+#ifdef NFP_STAMPS
+extern "C" int nfp_debug_set_stamp_buffer(void* dev_ptr) {
+  unsigned long long* p = (unsigned long long*)dev_ptr;
+  return hip_ok(hipMemcpyToSymbol(HIP_SYMBOL(nfp::nfp_stamp_buf), &p, sizeof(p)), "set stamp buffer");
+}
+#endif
 
 extern "C" {
 
