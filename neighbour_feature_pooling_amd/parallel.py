@@ -1,0 +1,56 @@
+"""Batch sharding of the NFP path across GPUs (one process per GPU).
+
+NFP is independent per image: ranks own disjoint slices of the batch and the data
+path has NO collective.  The only cross-rank traffic is what a caller asks for explicitly:
+`gather_batch` (to reassemble an output for checking) and `max_over_ranks` (bench timing).
+With torch.distributed backend "nccl" these run over RCCL/xGMI; tests use "gloo" on CPU.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n, rank, world):
+    """[lo, hi) of the `n` items rank `rank` of `world` owns; sizes differ by at most one."""
+    if world < 1 or not 0 <= rank < world:
+        raise ValueError(f"bad rank {rank} / world {world}")
+    base, rem = divmod(n, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def world_info():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def nfp_sharded(module, x_full):
+    """Run `module` (an NFPPooling) on this rank's slice of a batch every rank holds: returns
+    (local_out, (lo, hi)).  No communication."""
+    rank, world = world_info()
+    lo, hi = shard_range(x_full.shape[0], rank, world)
+    return module(x_full[lo:hi].contiguous()), (lo, hi)
+
+
+def gather_batch(local, total):
+    """All-gather ragged batch slices back into one [total, ...] tensor (test / debugging aid)."""
+    rank, world = world_info()
+    if world == 1:
+        return local
+    sizes = [shard_range(total, r, world) for r in range(world)]
+    mx = max(hi - lo for lo, hi in sizes)
+    pad = torch.zeros((mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[: local.shape[0]] = local
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad)
+    return torch.cat([parts[r][: hi - lo] for r, (lo, hi) in enumerate(sizes)], dim=0)
+
+
+def max_over_ranks(value, device=None):
+    """max of a python float over ranks (the bench's step time is the slowest rank's)."""
+    rank, world = world_info()
+    if world == 1:
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device or "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return t.item()
