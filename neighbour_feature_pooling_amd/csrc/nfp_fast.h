@@ -33,11 +33,30 @@
 
 namespace nfp {
 
-constexpr int kRB = 3;    // NCHW staging: 4x4 blocks per thread per chunk
+// tuning knobs (A/B tested with scripts/ab_flags.py; the defaults are the measured best)
+#ifndef NFP_RB
+#define NFP_RB 3
+#endif
+#ifndef NFP_FWD_THREADS
+#define NFP_FWD_THREADS 512
+#endif
+#ifndef NFP_BWD_THREADS
+#define NFP_BWD_THREADS 512
+#endif
+#ifndef NFP_UNROLL_F
+#define NFP_UNROLL_F 1
+#endif
+#ifndef NFP_A1_BARRIER
+#define NFP_A1_BARRIER 0
+#endif
+#ifndef NFP_UNROLL_B
+#define NFP_UNROLL_B 1
+#endif
+constexpr int kRB = NFP_RB;  // NCHW staging: 4x4 blocks per thread per chunk
 constexpr int kRT = 2;    // NCHW staging: tail (P % 4) pixel slots per thread per chunk
 constexpr int kRN = 8;    // channels-last staging: slots per thread per chunk
-constexpr int kFwdThreads = 512;   // every instruction costs (waves per SIMD) x 2 clk of CU issue time
-constexpr int kBwdThreads = 512;  // backward keeps (2R+1)^2 weights + offsets + staged x in registers
+constexpr int kFwdThreads = NFP_FWD_THREADS;  // every instruction costs (waves per SIMD) x 2 clk of CU issue time
+constexpr int kBwdThreads = NFP_BWD_THREADS;  // backward keeps (2R+1)^2 weights + offsets + staged x in registers
 
 template <int R>
 struct Win {
@@ -344,6 +363,7 @@ __global__ void __launch_bounds__(kFwdThreads) fwd_fast(const KP g, const void* 
       if (active && !(NFP_ABLATE & 1)) {
         // this thread's quads gl, gl+G, ... inside [done, upto)
         int cq = gl + ((max(done - gl, 0) + g.G - 1) / g.G) * g.G;
+#pragma unroll NFP_UNROLL_F
         for (; cq < upto; cq += g.G) {
           const float4* row = slab + cq * Pp + sp;
           const float4 a = row[0];
@@ -517,23 +537,37 @@ __global__ void __launch_bounds__(kBwdThreads) bwd_fast(const KP g, const void* 
       }
     }
   };
+#if !(NFP_ABLATE & 16)
   a1_load(gl);
+#endif
   __builtin_amdgcn_sched_barrier(0);  // keep these (small, needed first) loads ahead of the x chunk
+#if NFP_A1_BARRIER
+  // raw s_barrier (no waitcnt): every wave's coefficient loads enter the CU's memory queue before
+  // ANY wave's x loads, otherwise they queue behind the other waves' 16-byte loads
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+#endif
   Staged<NHWC> st;
+#if NFP_ABLATE & 64
+  __builtin_memset(&st, 0, sizeof(st));
+#else
   stage_issue<BF, NHWC>(st, xb, g, cb0, min(g.Cc, cb1 - cb0) >> 2, t, T, p, gl, active);
+#endif
   // nothing that consumes a loaded value may be scheduled above this line (hipcc otherwise hoists
   // e.g. rcp(|x_p|) into the load sequence and stalls the remaining loads behind a vmcnt wait)
   __builtin_amdgcn_sched_barrier(0);
   NFP_STAMP(1);
+#if !(NFP_ABLATE & 16)
   a1_math(gl);
   for (int n0 = gl + 4 * g.G; n0 < N; n0 += 4 * g.G) {
     a1_load(n0);
     a1_math(n0);
   }
+#endif
   __syncthreads();
   NFP_STAMP(2);
   // A2: gather.  Thread (r = p, slot j = gl, gl+G, ...), t = r + delta_j if inside the image.
-  if (active) {
+  if (active && !(NFP_ABLATE & 16)) {
     for (int j = gl; j < K2; j += g.G) {
       const int jy = j / K, jx = j - jy * K;
       const int ty = py + jy - R, tx = px + jx - R;
@@ -578,7 +612,7 @@ __global__ void __launch_bounds__(kBwdThreads) bwd_fast(const KP g, const void* 
   __syncthreads();
   NFP_STAMP(3);
   // A3: fold the neighbour-role self terms into the diagonal, fixed order
-  if (gl == 0) {
+  if (gl == 0 && !(NFP_ABLATE & 16)) {
     float s = Wt[p * K2 + K2 / 2];
 #pragma unroll
     for (int j = 0; j < K2; ++j) s += Sq2[p * K2 + j];
@@ -593,7 +627,7 @@ __global__ void __launch_bounds__(kBwdThreads) bwd_fast(const KP g, const void* 
     const int dy = j / K - R, dx = j % K - R;
     const bool ok = py + dy >= 0 && py + dy < g.H && px + dx >= 0 && px + dx < g.W;
     off[j] = ok ? swz(p + dy * g.W + dx) - swz(p) : 0;
-    w[j] = ok ? Wt[p * K2 + j] : 0.f;
+    w[j] = (NFP_ABLATE & 16) ? 0.1f * j : (ok ? Wt[p * K2 + j] : 0.f);
   }
   // B: one pass over the channel block
   for (int c0 = cb0; c0 < cb1; c0 += g.Cc) {
@@ -602,11 +636,14 @@ __global__ void __launch_bounds__(kBwdThreads) bwd_fast(const KP g, const void* 
       __syncthreads();
       stage_issue<BF, NHWC>(st, xb, g, c0, ncq, t, T, p, gl, active);
     }
+#if !(NFP_ABLATE & 64)
 #pragma unroll
     for (int part = 0; part < kRB; ++part) stage_commit<BF, NHWC>(st, slab, g, ncq, t, T, p, gl, active, part);
+#endif
     __syncthreads();
     NFP_STAMP(5);
-    if (active) {
+    if (active && !(NFP_ABLATE & 32)) {
+#pragma unroll NFP_UNROLL_B
       for (int cq = gl; cq < ncq; cq += g.G) {
         const float4* row = slab + cq * ((P + 3) & ~3) + swz(p);
         float4 r4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -618,7 +655,11 @@ __global__ void __launch_bounds__(kBwdThreads) bwd_fast(const KP g, const void* 
           r4.z = fmaf(w[j], q.z, r4.z);
           r4.w = fmaf(w[j], q.w, r4.w);
         }
+#if NFP_ABLATE & 128
+        asm volatile("" ::"v"(r4.x), "v"(r4.y), "v"(r4.z), "v"(r4.w));
+#else
         st4<BF, NHWC>(gxb, g, c0 + 4 * cq, p, r4);
+#endif
       }
     }
   }

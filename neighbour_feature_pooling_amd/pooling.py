@@ -14,9 +14,11 @@ from .nfp import NFPPooling
 class nfp_pooling(nn.Module):
     def __init__(self, nfp_layer=None, Params=None):
         super().__init__()
+        # NFP_Pooling.py:9 computes this only when nfp_layer is None, so the reference raises
+        # UnboundLocalError at line 23 when given BOTH a layer and Params; here that combination works.
+        dense_feature_dim = Params["num_ftrs"][Params["Model_name"]] if Params else 2048
         if nfp_layer is None:
-            # NFP_Pooling.py:9-16 — R=1, cosine, padding=1 are hard-coded there
-            dense_feature_dim = Params["num_ftrs"][Params["Model_name"]] if Params else 2048
+            # NFP_Pooling.py:10-16 — R=1, cosine, padding=1 are hard-coded there
             nfp_layer = NFPPooling(in_channels=dense_feature_dim, R=1, measure='cosine', padding=1,
                                    input_size=Params.get('input_size', 7) if Params else 7)
         self.nfp_layer = nfp_layer

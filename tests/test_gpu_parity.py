@@ -249,3 +249,61 @@ def test_no_grad_and_requires_grad_false(dev):
         a = m(x)
     b = m(x)
     assert not b.requires_grad and torch.equal(a, b)
+
+
+# ---- end-to-end configs (BASELINE.json configs 3 and 5 geometry) -------------------
+
+def test_resnet18_nfp_train_step_eurosat_shape(dev):
+    """Config 3: ResNet18+NFP(cosine) on 13-channel 64x64 input; NFP sees [B,512,2,2]."""
+    from neighbour_feature_pooling_amd import _abi
+    from neighbour_feature_pooling_amd.train import build, make_step, synthetic_batch
+    torch.manual_seed(0)
+    net = build("resnet18", num_classes=10, in_chans=13, image=64, device=dev)
+    step, _ = make_step(net)
+    x, y = synthetic_batch(32, 13, 64, 10, dev, torch.float32, 3)
+    n0 = _abi.load().nfp_launch_count()
+    l0 = step(x, y)
+    for _ in range(4):
+        l1 = step(x, y)
+    torch.cuda.synchronize()
+    assert _abi.load().nfp_launch_count() >= n0 + 10       # 5 x (fwd + bwd) through the HIP library
+    assert torch.isfinite(l1) and l1.item() < l0.item()
+
+
+def test_nfp_inside_network_matches_torch_formulation(dev):
+    """Gradients that flow back through the HIP NFP into a backbone equal those of the torch formulation."""
+    from neighbour_feature_pooling_amd import functional
+    from neighbour_feature_pooling_amd._host import nfp_host
+    from neighbour_feature_pooling_amd.train import build, synthetic_batch
+    torch.manual_seed(1)
+    net = build("resnet18", num_classes=6, in_chans=3, image=96, device=dev).eval()
+    x, y = synthetic_batch(8, 3, 96, 6, dev, torch.float32, 5)
+    crit = torch.nn.CrossEntropyLoss(label_smoothing=0.05)
+    crit(net(x), y).backward()
+    g_hip = {k: p.grad.clone() for k, p in net.named_parameters()}
+    net.zero_grad()
+    orig = functional._NfpHip.apply
+    try:
+        functional._NfpHip.apply = staticmethod(lambda t, cfg: nfp_host(t, cfg))  # torch ops on the GPU
+        crit(net(x), y).backward()
+    finally:
+        functional._NfpHip.apply = orig
+    for k, p in net.named_parameters():
+        ref = p.grad
+        assert (g_hip[k] - ref).abs().max().item() <= 2e-4 * max(ref.abs().max().item(), 1e-6), k
+
+
+def test_vit_tiny_nfp_bf16_k5_l2_step(dev):
+    """Config 5 geometry: ViT-Tiny tokens -> 14x14x192 grid, NFP k=5 L2, bf16 storage."""
+    from neighbour_feature_pooling_amd import NFPPooling, _abi
+    from neighbour_feature_pooling_amd.train import build, make_step, synthetic_batch
+    torch.manual_seed(0)
+    layer = NFPPooling(192, R=2, measure="norm", p=2, padding=2)
+    net = build("vit_tiny_patch16_224", num_classes=10, in_chans=3, image=224, nfp=layer, device=dev,
+                dtype=torch.bfloat16)
+    step, _ = make_step(net)
+    x, y = synthetic_batch(8, 3, 224, 10, dev, torch.bfloat16, 9)
+    losses = [step(x, y).item() for _ in range(3)]
+    torch.cuda.synchronize()
+    assert all(np.isfinite(losses))
+    assert _abi.load().nfp_last_variant().decode().startswith("bwd_fast<R2,l2,bf16")
