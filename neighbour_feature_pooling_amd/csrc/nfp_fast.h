@@ -46,6 +46,12 @@ namespace nfp {
 #ifndef NFP_UNROLL_F
 #define NFP_UNROLL_F 1
 #endif
+#ifndef NFP_STORE_MODE
+#define NFP_STORE_MODE 0  // grad_x stores: 0 plain, 1 nontemporal, 2 agent-scope (sc1, write-through)
+#endif
+#ifndef NFP_DIRECT_STORE
+#define NFP_DIRECT_STORE 1  // dword write-through stores straight from the compute loop (measured faster than the LDS-transposed 16-byte epilogue)
+#endif
 #ifndef NFP_A1_BARRIER
 #define NFP_A1_BARRIER 0
 #endif
@@ -119,28 +125,55 @@ __device__ __forceinline__ int swz(int p) { return (p & ~3) | (((p & 3) + (p >> 
 // integer division sequence
 __device__ __forceinline__ int fast_div(int i, float inv_d) { return (int)(((float)i + 0.5f) * inv_d); }
 
-// `x` is the (wave-uniform) image base, `e` a 32-bit element offset: hipcc then emits the
-// SGPR-base + VGPR-offset form of global_load with no 64-bit vector address arithmetic.
+// Image access goes through a buffer resource built from the wave-uniform image base: a 32-bit
+// byte voffset per lane plus an SGPR soffset (the channel-row stride), so the four channel rows of a
+// 4x4 block share ONE address VGPR and need no 64-bit vector arithmetic; stores can carry sc1
+// (write-through), which streams grad_x out during the kernel instead of in the end-of-kernel flush.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+using Rsrc = __amdgpu_buffer_rsrc_t;
+#ifndef NFP_STORE_AUX
+#define NFP_STORE_AUX 16  // 16 = sc1 (write-through), 0 = plain, 2 = nt
+#endif
+constexpr int kAuxSc1 = NFP_STORE_AUX;
+__device__ __forceinline__ Rsrc make_rsrc(const void* base, long long bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)(bytes > 0x7ffffff0LL ? 0x7ffffff0LL : bytes), 0x00020000);
+}
 template <bool BF>
-__device__ __forceinline__ float4 load_px4(const void* x, int e) {  // 4 consecutive elements
+__device__ __forceinline__ float4 load_px4(Rsrc r, int e, int srow) {  // 4 consecutive elements at element e (+ srow elems)
   if constexpr (!BF) {
-    return *(const float4*)((const float*)x + e);  // 4-byte aligned is enough for global_load_dwordx4
+    u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(r, e * 4, srow * 4, 0);
+    return make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w));
   } else {
-    uint2 u = *(const uint2*)((const uint16_t*)x + e);
-    float4 v;
-    v.x = __uint_as_float(u.x << 16);
-    v.y = __uint_as_float(u.x & 0xffff0000u);
-    v.z = __uint_as_float(u.y << 16);
-    v.w = __uint_as_float(u.y & 0xffff0000u);
-    return v;
+    u32x2 u = __builtin_amdgcn_raw_buffer_load_b64(r, e * 2, srow * 2, 0);
+    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                       __uint_as_float(u.y & 0xffff0000u));
   }
 }
 template <bool BF>
-__device__ __forceinline__ float load_1(const void* x, int e) {
+__device__ __forceinline__ float load_1(Rsrc r, int e, int srow) {
   if constexpr (!BF)
-    return ((const float*)x)[e];
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, e * 4, srow * 4, 0));
   else
-    return bf16_to_f32(((const uint16_t*)x)[e]);
+    return bf16_to_f32((uint16_t)__builtin_amdgcn_raw_buffer_load_b16(r, e * 2, srow * 2, 0));
+}
+template <bool BF>
+__device__ __forceinline__ void store_px4(Rsrc r, int e, int srow, float4 v) {  // write-through
+  if constexpr (!BF) {
+    u32x4 u = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+    __builtin_amdgcn_raw_buffer_store_b128(u, r, e * 4, srow * 4, kAuxSc1);
+  } else {
+    u32x2 u = {(uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16),
+               (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16)};
+    __builtin_amdgcn_raw_buffer_store_b64(u, r, e * 2, srow * 2, kAuxSc1);
+  }
+}
+template <bool BF>
+__device__ __forceinline__ void store_1(Rsrc r, int e, int srow, float v) {
+  if constexpr (!BF)
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, e * 4, srow * 4, kAuxSc1);
+  else
+    __builtin_amdgcn_raw_buffer_store_b16((short)f32_to_bf16(v), r, e * 2, srow * 2, kAuxSc1);
 }
 
 // Staged registers of one chunk.  Every load is unconditional (indices clamped onto valid slots);
@@ -160,8 +193,7 @@ struct Staged<true> {
 // NCHW issue order: tail pixels first, then block round 0, then block round 1 — data returns in
 // issue order, so the slab can be committed and consumed round by round while later loads fly.
 template <bool BF>
-__device__ __forceinline__ void stage_load(Staged<false>& s, const void* x, const KP& g, int c0, int ncq, int t,
-                                           int T) {
+__device__ __forceinline__ void stage_load(Staged<false>& s, Rsrc x, const KP& g, int c0, int ncq, int t, int T) {
   // straight-line: no branch may wrap a load (hipcc would wait for the loads inside it before
   // issuing the next ones).  P >= 4 is guaranteed by the dispatcher; with P % 4 == 0 the tail
   // loads degenerate to clamped duplicates of the last pixel and nothing is stored from them.
@@ -173,10 +205,10 @@ __device__ __forceinline__ void stage_load(Staged<false>& s, const void* x, cons
     const int i = max(min(t + r * T, ntl - 1), 0);
     const int cq = fast_div(i, invt), pt = i - cq * max(PT, 1);
     const int e = (c0 + 4 * cq) * P + min(4 * NQ + pt, P - 1);
-    s.tl[r].x = load_1<BF>(x, e);
-    s.tl[r].y = load_1<BF>(x, e + P);
-    s.tl[r].z = load_1<BF>(x, e + 2 * P);
-    s.tl[r].w = load_1<BF>(x, e + 3 * P);
+    s.tl[r].x = load_1<BF>(x, e, 0);
+    s.tl[r].y = load_1<BF>(x, e, P);
+    s.tl[r].z = load_1<BF>(x, e, 2 * P);
+    s.tl[r].w = load_1<BF>(x, e, 3 * P);
   }
 #pragma unroll
   for (int r = 0; r < kRB; ++r) {
@@ -184,7 +216,7 @@ __device__ __forceinline__ void stage_load(Staged<false>& s, const void* x, cons
     const int cq = fast_div(i, invq), pq = i - cq * NQ;
     const int e = (c0 + 4 * cq) * P + 4 * pq;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) s.blk[r][j] = load_px4<BF>(x, e + j * P);
+    for (int j = 0; j < 4; ++j) s.blk[r][j] = load_px4<BF>(x, e, j * P);
   }
 }
 // commit the tail slots and block round `r0..r1-1`
@@ -221,14 +253,14 @@ __device__ __forceinline__ void stage_store(const Staged<false>& s, float4* slab
 
 // channels-last: slot (cq, p) is 4 contiguous channels; thread (p, gl) takes cq = gl, gl+G, ...
 template <bool BF>
-__device__ __forceinline__ void stage_load(Staged<true>& s, const void* x, const KP& g, int c0, int ncq, int p,
-                                           int gl, bool active) {
+__device__ __forceinline__ void stage_load(Staged<true>& s, Rsrc x, const KP& g, int c0, int ncq, int p, int gl,
+                                           bool active) {
   const int g0 = active ? gl : 0;
   const int last = g0 < ncq ? g0 + ((ncq - 1 - g0) / g.G) * g.G : 0;
 #pragma unroll
   for (int k = 0; k < kRN; ++k) {
     const int cq = min(g0 + k * g.G, last);
-    s.v[k] = load_px4<BF>(x, p * g.C + c0 + 4 * cq);
+    s.v[k] = load_px4<BF>(x, p * g.C + c0 + 4 * cq, 0);
   }
 }
 __device__ __forceinline__ void stage_store(const Staged<true>& s, float4* slab, const KP& g, int ncq, int p, int gl,
@@ -241,8 +273,8 @@ __device__ __forceinline__ void stage_store(const Staged<true>& s, float4* slab,
 }
 
 template <bool BF, bool NHWC>
-__device__ __forceinline__ void stage_issue(Staged<NHWC>& s, const void* x, const KP& g, int c0, int ncq, int t,
-                                            int T, int p, int gl, bool active) {
+__device__ __forceinline__ void stage_issue(Staged<NHWC>& s, Rsrc x, const KP& g, int c0, int ncq, int t, int T,
+                                            int p, int gl, bool active) {
   if constexpr (NHWC)
     stage_load<BF>(s, x, g, c0, ncq, p, gl, active);
   else
@@ -261,37 +293,6 @@ __device__ __forceinline__ int stage_commit(const Staged<NHWC>& s, float4* slab,
     // committed so far are complete
     stage_store<BF>(s, slab, g, ncq, t, T, part == 0, part, part + 1);
     return part + 1 >= kRB ? ncq : min(ncq, ((part + 1) * T) / (g.P >> 2));
-  }
-}
-
-// grad_x slot (4 channels of pixel p); `x` is the image base, offsets are 32-bit
-template <bool BF, bool NHWC>
-__device__ __forceinline__ void st4(void* x, const KP& g, int c, int p, float4 v) {
-  if constexpr (!BF) {
-    float* s = (float*)x;
-    if constexpr (NHWC) {
-      *(float4*)(s + (p * g.C + c)) = v;
-    } else {
-      const int e = c * g.P + p;
-      s[e] = v.x;
-      s[e + g.P] = v.y;
-      s[e + 2 * g.P] = v.z;
-      s[e + 3 * g.P] = v.w;
-    }
-  } else {
-    uint16_t* s = (uint16_t*)x;
-    if constexpr (NHWC) {
-      uint2 u;
-      u.x = (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16);
-      u.y = (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16);
-      *(uint2*)(s + (p * g.C + c)) = u;
-    } else {
-      const int e = c * g.P + p;
-      s[e] = f32_to_bf16(v.x);
-      s[e + g.P] = f32_to_bf16(v.y);
-      s[e + 2 * g.P] = f32_to_bf16(v.z);
-      s[e + 3 * g.P] = f32_to_bf16(v.w);
-    }
   }
 }
 
@@ -314,7 +315,7 @@ __global__ void __launch_bounds__(kFwdThreads) fwd_fast(const KP g, const void* 
   const int py = fast_div(p, g.invW), px = p - py * g.W;
   const bool active = gl < g.G;
   constexpr int ES = BF ? 2 : 4;
-  const void* xb = (const char*)x + (long long)b * g.sB * ES;  // wave-uniform image base
+  const Rsrc xb = make_rsrc((const char*)x + (long long)b * g.sB * ES, (long long)g.C * P * ES);  // wave-uniform
 
   NFP_STAMP_INIT();
   NFP_STAMP(0);
@@ -467,8 +468,8 @@ __global__ void __launch_bounds__(kBwdThreads) bwd_fast(const KP g, const void* 
   const bool active = gl < g.G;
   constexpr int DT = BF ? NFP_BF16 : NFP_F32;
   constexpr int ES = BF ? 2 : 4;
-  const void* xb = (const char*)x + (long long)b * g.sB * ES;   // wave-uniform image bases
-  void* gxb = (char*)gx + (long long)b * g.sB * ES;
+  const Rsrc xb = make_rsrc((const char*)x + (long long)b * g.sB * ES, (long long)g.C * P * ES);  // wave-uniform
+  const Rsrc gxb = make_rsrc((char*)gx + (long long)b * g.sB * ES, (long long)g.C * P * ES);
   const void* gob = (const char*)go + (long long)b * N * P * ES;
   const void* outb = (const char*)out + (long long)b * N * P * ES;
 
@@ -629,7 +630,11 @@ __global__ void __launch_bounds__(kBwdThreads) bwd_fast(const KP g, const void* 
     off[j] = ok ? swz(p + dy * g.W + dx) - swz(p) : 0;
     w[j] = (NFP_ABLATE & 16) ? 0.1f * j : (ok ? Wt[p * K2 + j] : 0.f);
   }
-  // B: one pass over the channel block
+  // B: one pass over the channel block.  NCHW: results go to a second LDS slab and leave as 4x4
+  // blocks (four 16-byte write-through stores along the pixel axis); channels-last: one 16-byte
+  // write-through store per slot straight from registers.
+  const int Pp = (P + 3) & ~3, sp = swz(p);
+  float4* oslab = slab + (g.Cc >> 2) * Pp;
   for (int c0 = cb0; c0 < cb1; c0 += g.Cc) {
     const int ncq = min(g.Cc, cb1 - c0) >> 2;
     if (c0 > cb0) {
@@ -645,7 +650,7 @@ __global__ void __launch_bounds__(kBwdThreads) bwd_fast(const KP g, const void* 
     if (active && !(NFP_ABLATE & 32)) {
 #pragma unroll NFP_UNROLL_B
       for (int cq = gl; cq < ncq; cq += g.G) {
-        const float4* row = slab + cq * ((P + 3) & ~3) + swz(p);
+        const float4* row = slab + cq * Pp + sp;
         float4 r4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int j = 0; j < K2; ++j) {
@@ -658,8 +663,45 @@ __global__ void __launch_bounds__(kBwdThreads) bwd_fast(const KP g, const void* 
 #if NFP_ABLATE & 128
         asm volatile("" ::"v"(r4.x), "v"(r4.y), "v"(r4.z), "v"(r4.w));
 #else
-        st4<BF, NHWC>(gxb, g, c0 + 4 * cq, p, r4);
+        if constexpr (NHWC) {
+          store_px4<BF>(gxb, p * g.C + c0 + 4 * cq, 0, r4);
+        } else {
+#if NFP_DIRECT_STORE
+          const int e = (c0 + 4 * cq) * P + p;
+          store_1<BF>(gxb, e, 0, r4.x);
+          store_1<BF>(gxb, e, P, r4.y);
+          store_1<BF>(gxb, e, 2 * P, r4.z);
+          store_1<BF>(gxb, e, 3 * P, r4.w);
+#else
+          oslab[cq * Pp + sp] = r4;
 #endif
+        }
+#endif
+      }
+    }
+    if constexpr (!NHWC && !NFP_DIRECT_STORE) {
+      __syncthreads();
+      const int NQ = P >> 2, PT = P & 3;
+      const int nblk = ncq * NQ, ntl = ncq * PT;
+      for (int i = t; i < nblk; i += T) {
+        const int cq = fast_div(i, g.invNQ), pq = i - cq * NQ;
+        const float4* d = oslab + cq * Pp + 4 * pq;
+        const int rot = (pq >> 1) & 3;
+        const float4 a0 = d[rot], a1 = d[(rot + 1) & 3], a2 = d[(rot + 2) & 3], a3 = d[(rot + 3) & 3];
+        const int e = (c0 + 4 * cq) * P + 4 * pq;
+        store_px4<BF>(gxb, e, 0, make_float4(a0.x, a1.x, a2.x, a3.x));
+        store_px4<BF>(gxb, e, P, make_float4(a0.y, a1.y, a2.y, a3.y));
+        store_px4<BF>(gxb, e, 2 * P, make_float4(a0.z, a1.z, a2.z, a3.z));
+        store_px4<BF>(gxb, e, 3 * P, make_float4(a0.w, a1.w, a2.w, a3.w));
+      }
+      for (int i = t; i < ntl; i += T) {
+        const int cq = fast_div(i, g.invPT), pt = i - cq * PT;
+        const float4 a = oslab[cq * Pp + swz(4 * NQ + pt)];
+        const int e = (c0 + 4 * cq) * P + 4 * NQ + pt;
+        store_1<BF>(gxb, e, 0, a.x);
+        store_1<BF>(gxb, e, P, a.y);
+        store_1<BF>(gxb, e, 2 * P, a.z);
+        store_1<BF>(gxb, e, 3 * P, a.w);
       }
     }
   }

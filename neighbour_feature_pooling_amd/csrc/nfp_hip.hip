@@ -153,7 +153,7 @@ int launch_bwd_generic(KP g, const void* x, const void* go, const void* out, con
 
 // ---- fast-path launches (nfp_fast.h) ----------------------------------------------------------
 constexpr int kSlabBudgetFwd = 128 * 1024;
-constexpr int kSlabBudgetBwd = 96 * 1024;
+constexpr int kSlabBudgetBwd = 60 * 1024;  // x slab; the NCHW backward keeps a result slab of the same size
 
 bool force_generic() {
   const char* e = getenv("NFP_FORCE_GENERIC");
@@ -252,7 +252,10 @@ int launch_bwd_fast_t(KP g, const void* x, const void* go, const void* out, cons
   size_t wt = (size_t)g.P * K2 * 4;
   size_t tables = (size_t)(4 * g.P * N + g.P * K2) * 4;
   size_t slab = (size_t)(g.Cc / 4) * ((g.P + 3) & ~3) * 16;
-  size_t lds = ((wt + 15) & ~(size_t)15) + (slab > tables ? slab : tables);
+  size_t xs = slab > tables ? slab : tables;
+  if (!NHWC && xs < 2 * slab) xs = 2 * slab;  // + result slab
+  if (!NHWC && tables > slab) xs = tables > 2 * slab ? tables : 2 * slab;
+  size_t lds = ((wt + 15) & ~(size_t)15) + xs;
   if (lds > (size_t)kLdsMax) return fail(NFP_E_UNSUPPORTED, "bwd_fast: LDS %zu", lds);
   if (int rc = set_lds(bwd_fast<R, M, BF, NHWC>, lds)) return rc;
   hipLaunchKernelGGL((bwd_fast<R, M, BF, NHWC>), dim3(g.B, S), dim3(T), lds, st, g, x, go, out, saved, gx);
