@@ -19,6 +19,7 @@ struct KP {
   int R, k, N, pad, stride, dil, mode;
   int Ho, Wo, O;  // O = Ho*Wo outputs per neighbour map
   int measure, similarity, diff, dtype;
+  int godtype;  // dtype of the grad_out the backward kernel reads (f32 scratch for Attention)
   float p, eps, q_scs;
   long long sB, sC, sH, sW;  // element strides of x / grad_x
   int contig;                // x is NCHW-contiguous

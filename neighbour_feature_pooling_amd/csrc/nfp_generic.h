@@ -187,13 +187,19 @@ __global__ void __launch_bounds__(1024) fwd_generic(const KP g, const void* __re
       }
     }
     if constexpr (Meas<M>::NSTAT > 0) if (saved != nullptr) {
-      // per-input-pixel stats for backward; several threads may store the same pixel, all
-      // with a value summed in the same order (benign duplicate stores)
+      // per-input-pixel stats for backward, [B][NSTAT][P]; several threads may store the same pixel,
+      // all with a value summed in the same order (benign duplicate stores)
       float* sv = saved + (long long)b * Meas<M>::NSTAT * g.P;
-      if (pc >= 0) sv[pc] = Meas<M>::save0(sa0);
+      if (pc >= 0) {
+        sv[pc] = Meas<M>::save0(sa0, sa1, g);
+        if (Meas<M>::NSTAT > 1) sv[g.P + pc] = Meas<M>::save1(sa0, sa1, g);
+      }
 #pragma unroll
       for (int j = 0; j < kGroup; ++j)
-        if (q[j] >= 0) sv[q[j]] = Meas<M>::save0(sb0[j]);
+        if (q[j] >= 0) {
+          sv[q[j]] = Meas<M>::save0(sb0[j], sb1[j], g);
+          if (Meas<M>::NSTAT > 1) sv[g.P + q[j]] = Meas<M>::save1(sb0[j], sb1[j], g);
+        }
     }
   }
 }
@@ -225,6 +231,7 @@ __global__ void __launch_bounds__(1024) bwd_generic(const KP g, const void* __re
       if (!active) continue;
       const int pc = tap_pixel(g, o, g.R, g.R);
       const float sp0 = (Meas<M>::NSTAT > 0 && pc >= 0) ? sv[pc] : 0.f;
+      const float sp1 = (Meas<M>::NSTAT > 1 && pc >= 0) ? sv[g.P + pc] : 0.f;
       for (int grp = 0; grp < ngrp; ++grp) {
         int q[kGroup];
         Coef cf[kGroup];
@@ -236,7 +243,8 @@ __global__ void __launch_bounds__(1024) bwd_generic(const KP g, const void* __re
             q[j] = nbr_pixel(g, o, n);
             long long oi = ((long long)b * g.N + n) * g.O + o;
             float sq0 = (Meas<M>::NSTAT > 0 && q[j] >= 0) ? sv[q[j]] : 0.f;
-            cf[j] = Meas<M>::coef(ldx(go, oi, g.dtype), ldx(out, oi, g.dtype), sp0, 0.f, sq0, 0.f, g);
+            float sq1 = (Meas<M>::NSTAT > 1 && q[j] >= 0) ? sv[g.P + q[j]] : 0.f;
+            cf[j] = Meas<M>::coef(ldx(go, oi, g.godtype), ldx(out, oi, g.dtype), sp0, sp1, sq0, sq1, g);
           }
         }
         for (int c = cl; c < cc; c += g.Tc) {
@@ -260,6 +268,42 @@ __global__ void __launch_bounds__(1024) bwd_generic(const KP g, const void* __re
     }
     __syncthreads();
     unstage_chunk(ga, gx, g, b, c0, cc);
+  }
+}
+
+// ---- Attention (nfp.py:195-205): softmax over the N neighbour maps, in place on out[b, :, o] ------
+__global__ void __launch_bounds__(256) attn_softmax_fwd(const KP g, void* __restrict__ out) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // (b, o)
+  if (i >= (long long)g.B * g.O) return;
+  const long long b = i / g.O, o = i - b * g.O;
+  const long long base = b * g.N * g.O + o;
+  float mx = -INFINITY;
+  for (int n = 0; n < g.N; ++n) mx = fmaxf(mx, ldx(out, base + (long long)n * g.O, g.dtype));
+  float s = 0.f;
+  for (int n = 0; n < g.N; ++n) s += expf(ldx(out, base + (long long)n * g.O, g.dtype) - mx);
+  const float sg = g.similarity ? 1.f : -1.f;
+  for (int n = 0; n < g.N; ++n) {
+    float y = expf(ldx(out, base + (long long)n * g.O, g.dtype) - mx) / s;
+    stx(out, base + (long long)n * g.O, sg * y, g.dtype);
+  }
+}
+// grad wrt the dots: gd_n = y_n * (gy_n - sum_m gy_m y_m), out = +-y  ->  scratch (f32)
+__global__ void __launch_bounds__(256) attn_softmax_bwd(const KP g, const void* __restrict__ go,
+                                                        const void* __restrict__ out, float* __restrict__ gd) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)g.B * g.O) return;
+  const long long b = i / g.O, o = i - b * g.O;
+  const long long base = b * g.N * g.O + o;
+  const float sg = g.similarity ? 1.f : -1.f;
+  float dot = 0.f;
+  for (int n = 0; n < g.N; ++n) {
+    long long k = base + (long long)n * g.O;
+    dot += sg * ldx(go, k, g.dtype) * sg * ldx(out, k, g.dtype);
+  }
+  for (int n = 0; n < g.N; ++n) {
+    long long k = base + (long long)n * g.O;
+    float y = sg * ldx(out, k, g.dtype);
+    gd[k] = y * (sg * ldx(go, k, g.dtype) - dot);
   }
 }
 

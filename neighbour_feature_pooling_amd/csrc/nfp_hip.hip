@@ -71,6 +71,7 @@ int make_kp(const nfp_desc* d, KP* g) {
   g->Wo = (d->W + 2 * d->pad - span) / d->stride + 1;
   g->O = g->Ho * g->Wo;
   g->measure = d->measure; g->similarity = d->similarity != 0; g->diff = d->diff_weights != 0; g->dtype = d->dtype;
+  g->godtype = d->dtype;
   g->p = d->p; g->eps = d->eps; g->q_scs = d->q_scs;
   g->sB = d->sxB; g->sC = d->sxC; g->sH = d->sxH; g->sW = d->sxW;
   g->contig = (d->sxW == 1 && d->sxH == d->W && d->sxC == (int64_t)d->H * d->W) ? 1 : 0;
@@ -84,9 +85,11 @@ int make_kp(const nfp_desc* d, KP* g) {
   return NFP_OK;
 }
 
+// floats per input pixel that forward hands to backward
 int stats_of(int measure) {
   switch (measure) {
-    case NFP_COSINE: return 1;
+    case NFP_COSINE: case NFP_GFC: case NFP_SMITH: return 1;
+    case NFP_PEARSON: return 2;
     default: return 0;
   }
 }
@@ -303,6 +306,7 @@ int nfp_output_shape(const nfp_desc* d, int32_t* N, int32_t* Ho, int32_t* Wo) {
 int64_t nfp_saved_floats(const nfp_desc* d) {
   KP g;
   if (make_kp(d, &g)) return -1;
+  if (g.measure == NFP_ATTENTION) return (int64_t)g.B * g.N * g.O;  // backward scratch: grad wrt the dots
   return (int64_t)stats_of(g.measure) * g.B * g.P;
 }
 
@@ -322,7 +326,33 @@ int nfp_forward(const nfp_desc* d, const void* x, void* out, float* saved, void*
   switch (g.measure) {
     case NFP_COSINE: return launch_fwd_generic<NFP_COSINE>(g, x, out, saved, st);
     case NFP_NORM: return launch_fwd_generic<NFP_NORM>(g, x, out, saved, st);
-    default: return fail(NFP_E_UNSUPPORTED, "measure %d has no HIP kernel yet", g.measure);
+    case NFP_DOT: return launch_fwd_generic<NFP_DOT>(g, x, out, saved, st);
+    case NFP_RMSE: return launch_fwd_generic<NFP_RMSE>(g, x, out, saved, st);
+    case NFP_GEMAN: return launch_fwd_generic<NFP_GEMAN>(g, x, out, saved, st);
+    case NFP_EMD: return launch_fwd_generic<NFP_EMD>(g, x, out, saved, st);
+    case NFP_CANBERRA: return launch_fwd_generic<NFP_CANBERRA>(g, x, out, saved, st);
+    case NFP_HELLINGER: return launch_fwd_generic<NFP_HELLINGER>(g, x, out, saved, st);
+    case NFP_CHISQUARED1: return launch_fwd_generic<NFP_CHISQUARED1>(g, x, out, saved, st);
+    case NFP_CHISQUARED2: return launch_fwd_generic<NFP_CHISQUARED2>(g, x, out, saved, st);
+    case NFP_GFC: return launch_fwd_generic<NFP_GFC>(g, x, out, saved, st);
+    case NFP_PEARSON: return launch_fwd_generic<NFP_PEARSON>(g, x, out, saved, st);
+    case NFP_JEFFREY: return launch_fwd_generic<NFP_JEFFREY>(g, x, out, saved, st);
+    case NFP_SQUAREDCHORD: return launch_fwd_generic<NFP_SQUAREDCHORD>(g, x, out, saved, st);
+    case NFP_SMITH: return launch_fwd_generic<NFP_SMITH>(g, x, out, saved, st);
+    case NFP_ATTENTION: {
+      if (g.dtype != NFP_F32) return fail(NFP_E_UNSUPPORTED, "attention: float32 only");
+      KP gd = g;
+      gd.similarity = 1;  // raw dots first; the sign belongs to the softmax output (nfp.py:203-204)
+      if (int rc = launch_fwd_generic<NFP_DOT>(gd, x, out, nullptr, st)) return rc;
+      const long long n = (long long)g.B * g.O;
+      hipLaunchKernelGGL(attn_softmax_fwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, g, out);
+      g_launches++;
+      snprintf(g_variant, sizeof(g_variant), "fwd_generic+attn_softmax");
+      return hip_ok(hipGetLastError(), "launch attn_softmax_fwd");
+    }
+    default:
+      return fail(NFP_E_UNSUPPORTED, "measure %d (SharpenedCosine mixes batch elements in the reference, "
+                  "nfp.py:359-374) has no HIP kernel", g.measure);
   }
 }
 
@@ -331,7 +361,7 @@ int nfp_backward(const nfp_desc* d, const void* x, const void* grad_out, const v
   KP g;
   if (int rc = make_kp(d, &g)) return rc;
   if (!x || !grad_out || !out || !grad_x) return fail(NFP_E_INVALID, "null tensor pointer");
-  if (stats_of(g.measure) > 0 && !saved) return fail(NFP_E_INVALID, "measure %d needs the saved state of nfp_forward", g.measure);
+  if ((stats_of(g.measure) > 0 || g.measure == NFP_ATTENTION) && !saved) return fail(NFP_E_INVALID, "measure %d needs the saved state of nfp_forward", g.measure);
   if (g.B == 0) return NFP_OK;
   hipStream_t st = (hipStream_t)hip_stream;
   if (fast_ok(g, x, grad_x)) {
@@ -344,7 +374,33 @@ int nfp_backward(const nfp_desc* d, const void* x, const void* grad_out, const v
   switch (g.measure) {
     case NFP_COSINE: return launch_bwd_generic<NFP_COSINE>(g, x, grad_out, out, saved, grad_x, st);
     case NFP_NORM: return launch_bwd_generic<NFP_NORM>(g, x, grad_out, out, saved, grad_x, st);
-    default: return fail(NFP_E_UNSUPPORTED, "measure %d has no HIP kernel yet", g.measure);
+    case NFP_DOT: return launch_bwd_generic<NFP_DOT>(g, x, grad_out, out, saved, grad_x, st);
+    case NFP_RMSE: return launch_bwd_generic<NFP_RMSE>(g, x, grad_out, out, saved, grad_x, st);
+    case NFP_GEMAN: return launch_bwd_generic<NFP_GEMAN>(g, x, grad_out, out, saved, grad_x, st);
+    case NFP_EMD: return launch_bwd_generic<NFP_EMD>(g, x, grad_out, out, saved, grad_x, st);
+    case NFP_CANBERRA: return launch_bwd_generic<NFP_CANBERRA>(g, x, grad_out, out, saved, grad_x, st);
+    case NFP_HELLINGER: return launch_bwd_generic<NFP_HELLINGER>(g, x, grad_out, out, saved, grad_x, st);
+    case NFP_CHISQUARED1: return launch_bwd_generic<NFP_CHISQUARED1>(g, x, grad_out, out, saved, grad_x, st);
+    case NFP_CHISQUARED2: return launch_bwd_generic<NFP_CHISQUARED2>(g, x, grad_out, out, saved, grad_x, st);
+    case NFP_GFC: return launch_bwd_generic<NFP_GFC>(g, x, grad_out, out, saved, grad_x, st);
+    case NFP_PEARSON: return launch_bwd_generic<NFP_PEARSON>(g, x, grad_out, out, saved, grad_x, st);
+    case NFP_JEFFREY: return launch_bwd_generic<NFP_JEFFREY>(g, x, grad_out, out, saved, grad_x, st);
+    case NFP_SQUAREDCHORD: return launch_bwd_generic<NFP_SQUAREDCHORD>(g, x, grad_out, out, saved, grad_x, st);
+    case NFP_SMITH: return launch_bwd_generic<NFP_SMITH>(g, x, grad_out, out, saved, grad_x, st);
+    case NFP_ATTENTION: {
+      if (g.dtype != NFP_F32) return fail(NFP_E_UNSUPPORTED, "attention: float32 only");
+      float* gd = const_cast<float*>(saved);  // scratch handed over by nfp_forward's caller (nfp_saved_floats)
+      const long long n = (long long)g.B * g.O;
+      hipLaunchKernelGGL(attn_softmax_bwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, g, grad_out, out, gd);
+      g_launches++;
+      if (int rc = hip_ok(hipGetLastError(), "launch attn_softmax_bwd")) return rc;
+      KP gdot = g;
+      gdot.similarity = 1;
+      gdot.godtype = NFP_F32;
+      return launch_bwd_generic<NFP_DOT>(gdot, x, gd, out, nullptr, grad_x, st);
+    }
+    default:
+      return fail(NFP_E_UNSUPPORTED, "measure %d (SharpenedCosine) has no HIP kernel", g.measure);
   }
 }
 

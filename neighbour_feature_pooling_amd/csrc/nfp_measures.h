@@ -15,7 +15,7 @@
 namespace nfp {
 
 struct Coef {
-  float k0, k1, k2, k3;
+  float k0, k1, k2, k3, k4;
 };
 
 template <int M>
@@ -40,7 +40,7 @@ struct Meas<NFP_NORM> {
   __device__ static __forceinline__ Coef coef(float go, float outv, float, float, float, float, const KP& g) {
     float d = fabsf(outv);
     float sg = g.similarity ? -go : go;
-    Coef c = {0.f, 0.f, 0.f, 0.f};
+    Coef c = {0.f, 0.f, 0.f, 0.f, 0.f};
     if (g.p == 1.f)
       c.k0 = sg;
     else if (g.p == 2.f)
@@ -78,8 +78,9 @@ struct Meas<NFP_COSINE> {
     float s = acc * ia * ib;
     return g.similarity ? s : 1.f - s;
   }
-  // saved stat -> what is stored for backward
-  __device__ static __forceinline__ float save0(float s0) { return sqrtf(s0); }
+  // accumulated stats -> what is stored per pixel for backward
+  __device__ static __forceinline__ float save0(float s0, float, const KP&) { return sqrtf(s0); }
+  __device__ static __forceinline__ float save1(float, float, const KP&) { return 0.f; }
   __device__ static __forceinline__ Coef coef(float go, float outv, float np, float, float nq, float, const KP& g) {
     float s = g.similarity ? outv : 1.f - outv;
     float sg = g.similarity ? go : -go;
@@ -89,7 +90,7 @@ struct Meas<NFP_COSINE> {
     c.k0 = sg * ip * iq;      // cross term
     c.k1 = sg * s * rp * ip;  // centre self term
     c.k2 = sg * s * rq * iq;  // neighbour self term
-    c.k3 = 0.f;
+    c.k3 = c.k4 = 0.f;
     return c;
   }
   __device__ static __forceinline__ void grad(float a, float b, const Coef& c, const KP&, float& da, float& db) {
@@ -97,5 +98,300 @@ struct Meas<NFP_COSINE> {
     db = c.k0 * a - c.k2 * b;
   }
 };
+
+
+// Helper: sign convention shared by the "distance" measures (negated when similarity=True).
+__device__ __forceinline__ float dist_sign(const KP& g, float go) { return g.similarity ? -go : go; }
+
+// ---- DotProduct   nfp.py:161-170 ------------------------------------------------------------
+template <>
+struct Meas<NFP_DOT> {
+  static constexpr int NSTAT = 0;
+  __device__ static __forceinline__ float term(float a, float b, const KP&) { return a * b; }
+  __device__ static __forceinline__ void stat(float, float&, float&) {}
+  __device__ static __forceinline__ float fin(float acc, float, float, float, float, const KP& g) {
+    return g.similarity ? acc : -acc;
+  }
+  __device__ static __forceinline__ Coef coef(float go, float, float, float, float, float, const KP& g) {
+    Coef c = {g.similarity ? go : -go, 0.f, 0.f, 0.f, 0.f};
+    return c;
+  }
+  __device__ static __forceinline__ void grad(float a, float b, const Coef& c, const KP&, float& da, float& db) {
+    da = c.k0 * b;
+    db = c.k0 * a;
+  }
+};
+
+// ---- RMSE   nfp.py:172-179 (conv weights as Norm: nfp.py:74-80) --------------------------------
+template <>
+struct Meas<NFP_RMSE> {
+  static constexpr int NSTAT = 0;
+  __device__ static __forceinline__ float term(float a, float b, const KP& g) {
+    float v = g.diff ? a - b : b;
+    return v * v;
+  }
+  __device__ static __forceinline__ void stat(float, float&, float&) {}
+  __device__ static __forceinline__ float fin(float acc, float, float, float, float, const KP& g) {
+    float d = sqrtf(acc / (float)g.C);
+    return g.similarity ? -d : d;
+  }
+  __device__ static __forceinline__ Coef coef(float go, float outv, float, float, float, float, const KP& g) {
+    // d sqrt(m)/dm * dm/dv = v / (d*C); d == 0 gives inf here and inf*0 = NaN below, exactly as torch
+    Coef c = {dist_sign(g, go) / (fabsf(outv) * (float)g.C), 0.f, 0.f, 0.f, 0.f};
+    return c;
+  }
+  __device__ static __forceinline__ void grad(float a, float b, const Coef& c, const KP& g, float& da, float& db) {
+    float t = c.k0 * (g.diff ? a - b : b);
+    da = g.diff ? t : 0.f;
+    db = g.diff ? -t : t;
+  }
+};
+
+// ---- Geman-McClure   nfp.py:181-193 -----------------------------------------------------------
+template <>
+struct Meas<NFP_GEMAN> {
+  static constexpr int NSTAT = 0;
+  __device__ static __forceinline__ float term(float a, float b, const KP& g) {
+    float q = (a - b) * (a - b);
+    return q / (q + g.eps);
+  }
+  __device__ static __forceinline__ void stat(float, float&, float&) {}
+  __device__ static __forceinline__ float fin(float acc, float, float, float, float, const KP& g) {
+    float f = acc / (float)g.C;
+    return g.similarity ? f : 1.f - f;
+  }
+  __device__ static __forceinline__ Coef coef(float go, float, float, float, float, float, const KP& g) {
+    Coef c = {(g.similarity ? go : -go) / (float)g.C, 0.f, 0.f, 0.f, 0.f};
+    return c;
+  }
+  __device__ static __forceinline__ void grad(float a, float b, const Coef& c, const KP& g, float& da, float& db) {
+    float v = a - b, q = v * v + g.eps;
+    da = c.k0 * 2.f * v * g.eps / (q * q);
+    db = -da;
+  }
+};
+
+// ---- EMD (L1)   nfp.py:207-216 ----------------------------------------------------------------
+template <>
+struct Meas<NFP_EMD> {
+  static constexpr int NSTAT = 0;
+  __device__ static __forceinline__ float term(float a, float b, const KP&) { return fabsf(a - b); }
+  __device__ static __forceinline__ void stat(float, float&, float&) {}
+  __device__ static __forceinline__ float fin(float acc, float, float, float, float, const KP& g) {
+    return g.similarity ? -acc : acc;
+  }
+  __device__ static __forceinline__ Coef coef(float go, float, float, float, float, float, const KP& g) {
+    Coef c = {dist_sign(g, go), 0.f, 0.f, 0.f, 0.f};
+    return c;
+  }
+  __device__ static __forceinline__ void grad(float a, float b, const Coef& c, const KP&, float& da, float& db) {
+    da = c.k0 * sgnf(a - b);
+    db = -da;
+  }
+};
+
+// ---- Canberra   nfp.py:218-227 ----------------------------------------------------------------
+template <>
+struct Meas<NFP_CANBERRA> {
+  static constexpr int NSTAT = 0;
+  __device__ static __forceinline__ float term(float a, float b, const KP& g) {
+    return fabsf(a - b) / (fabsf(a) + fabsf(b) + g.eps);
+  }
+  __device__ static __forceinline__ void stat(float, float&, float&) {}
+  __device__ static __forceinline__ float fin(float acc, float, float, float, float, const KP& g) {
+    return g.similarity ? -acc : acc;
+  }
+  __device__ static __forceinline__ Coef coef(float go, float, float, float, float, float, const KP& g) {
+    Coef c = {dist_sign(g, go), 0.f, 0.f, 0.f, 0.f};
+    return c;
+  }
+  __device__ static __forceinline__ void grad(float a, float b, const Coef& c, const KP& g, float& da, float& db) {
+    float u = fabsf(a - b), w = fabsf(a) + fabsf(b) + g.eps, s = sgnf(a - b);
+    da = c.k0 * (s / w - u * sgnf(a) / (w * w));
+    db = c.k0 * (-s / w - u * sgnf(b) / (w * w));
+  }
+};
+
+// ---- Hellinger nfp.py:229-241 / SquaredChord nfp.py:310-324 -------------------------------------
+template <int WHICH>
+struct MeasChord {
+  static constexpr int NSTAT = 0;
+  __device__ static __forceinline__ float term(float a, float b, const KP& g) {
+    float r = sqrtf(fabsf(a) + g.eps) - sqrtf(fabsf(b) + g.eps);
+    return r * r;
+  }
+  __device__ static __forceinline__ void stat(float, float&, float&) {}
+  __device__ static __forceinline__ float fin(float acc, float, float, float, float, const KP& g) {
+    float f = WHICH == NFP_HELLINGER ? sqrtf(0.5f * acc) : acc;
+    return g.similarity ? -f : f;
+  }
+  __device__ static __forceinline__ Coef coef(float go, float outv, float, float, float, float, const KP& g) {
+    // Hellinger: d sqrt(S/2)/dS = 0.25/f (inf at f == 0 -> NaN below, as torch)
+    Coef c = {dist_sign(g, go) * (WHICH == NFP_HELLINGER ? 0.25f / fabsf(outv) : 1.f), 0.f, 0.f, 0.f, 0.f};
+    return c;
+  }
+  __device__ static __forceinline__ void grad(float a, float b, const Coef& c, const KP& g, float& da, float& db) {
+    float ra = sqrtf(fabsf(a) + g.eps), rb = sqrtf(fabsf(b) + g.eps);
+    da = c.k0 * ((ra - rb) / ra) * sgnf(a);
+    db = c.k0 * (-(ra - rb) / rb) * sgnf(b);
+  }
+};
+template <>
+struct Meas<NFP_HELLINGER> : MeasChord<NFP_HELLINGER> {};
+template <>
+struct Meas<NFP_SQUAREDCHORD> : MeasChord<NFP_SQUAREDCHORD> {};
+
+// ---- Chi-squared 1 / 2   nfp.py:243-263 ---------------------------------------------------------
+template <int WHICH>
+struct MeasChi {
+  static constexpr int NSTAT = 0;
+  __device__ static __forceinline__ float wden(float a, float b, const KP& g) {
+    return fabsf(a) + (WHICH == NFP_CHISQUARED1 ? fabsf(b) : 0.f) + g.eps;
+  }
+  __device__ static __forceinline__ float term(float a, float b, const KP& g) {
+    float v = a - b;
+    return v * v / wden(a, b, g);
+  }
+  __device__ static __forceinline__ void stat(float, float&, float&) {}
+  __device__ static __forceinline__ float fin(float acc, float, float, float, float, const KP& g) {
+    return g.similarity ? -acc : acc;
+  }
+  __device__ static __forceinline__ Coef coef(float go, float, float, float, float, float, const KP& g) {
+    Coef c = {dist_sign(g, go), 0.f, 0.f, 0.f, 0.f};
+    return c;
+  }
+  __device__ static __forceinline__ void grad(float a, float b, const Coef& c, const KP& g, float& da, float& db) {
+    float v = a - b, w = wden(a, b, g);
+    da = c.k0 * (2.f * v / w - v * v * sgnf(a) / (w * w));
+    db = c.k0 * (-2.f * v / w - (WHICH == NFP_CHISQUARED1 ? v * v * sgnf(b) / (w * w) : 0.f));
+  }
+};
+template <>
+struct Meas<NFP_CHISQUARED1> : MeasChi<NFP_CHISQUARED1> {};
+template <>
+struct Meas<NFP_CHISQUARED2> : MeasChi<NFP_CHISQUARED2> {};
+
+// ---- GFC   nfp.py:265-276: dot / (|a||b| + eps) ---------------------------------------------------
+template <>
+struct Meas<NFP_GFC> {
+  static constexpr int NSTAT = 1;  // saved[0] = |a|
+  __device__ static __forceinline__ float term(float a, float b, const KP&) { return a * b; }
+  __device__ static __forceinline__ void stat(float a, float& s0, float&) { s0 = fmaf(a, a, s0); }
+  __device__ static __forceinline__ float fin(float acc, float sa0, float, float sb0, float, const KP& g) {
+    float f = acc / (sqrtf(sa0) * sqrtf(sb0) + g.eps);
+    return g.similarity ? f : -f;
+  }
+  __device__ static __forceinline__ float save0(float s0, float, const KP&) { return sqrtf(s0); }
+  __device__ static __forceinline__ float save1(float, float, const KP&) { return 0.f; }
+  __device__ static __forceinline__ Coef coef(float go, float outv, float np, float, float nq, float, const KP& g) {
+    const float sg = g.similarity ? 1.f : -1.f;
+    const float den = np * nq + g.eps, num = sg * outv * den;
+    Coef c;
+    c.k0 = go * sg / den;
+    c.k1 = np > 0.f ? go * sg * num * nq / (den * den * np) : 0.f;
+    c.k2 = nq > 0.f ? go * sg * num * np / (den * den * nq) : 0.f;
+    c.k3 = c.k4 = 0.f;
+    return c;
+  }
+  __device__ static __forceinline__ void grad(float a, float b, const Coef& c, const KP&, float& da, float& db) {
+    da = c.k0 * b - c.k1 * a;
+    db = c.k0 * a - c.k2 * b;
+  }
+};
+
+// ---- Pearson   nfp.py:278-293 -------------------------------------------------------------------
+template <>
+struct Meas<NFP_PEARSON> {
+  static constexpr int NSTAT = 2;  // saved[0] = mean(a), saved[1] = sum (a-mean)^2
+  __device__ static __forceinline__ float term(float a, float b, const KP&) { return a * b; }
+  __device__ static __forceinline__ void stat(float a, float& s0, float& s1) {
+    s0 += a;
+    s1 = fmaf(a, a, s1);
+  }
+  __device__ static __forceinline__ float fin(float acc, float sa0, float sa1, float sb0, float sb1, const KP& g) {
+    const float C = (float)g.C, ma = sa0 / C, mb = sb0 / C;
+    const float sab = acc - C * ma * mb, saa = sa1 - C * ma * ma, sbb = sb1 - C * mb * mb;
+    const float f = sab / sqrtf(saa * sbb + g.eps);
+    return g.similarity ? f : -f;
+  }
+  __device__ static __forceinline__ float save0(float s0, float, const KP& g) { return s0 / (float)g.C; }
+  __device__ static __forceinline__ float save1(float s0, float s1, const KP& g) { return s1 - s0 * s0 / (float)g.C; }
+  __device__ static __forceinline__ Coef coef(float go, float outv, float mp, float saa, float mq, float sbb,
+                                              const KP& g) {
+    const float sg = g.similarity ? 1.f : -1.f;
+    const float den = sqrtf(saa * sbb + g.eps), sab = sg * outv * den, d3 = den * den * den;
+    Coef c;
+    c.k0 = sg * go / den;
+    c.k1 = sg * go * sab * sbb / d3;
+    c.k2 = sg * go * sab * saa / d3;
+    c.k3 = mp;
+    c.k4 = mq;
+    return c;
+  }
+  __device__ static __forceinline__ void grad(float a, float b, const Coef& c, const KP&, float& da, float& db) {
+    const float ac = a - c.k3, bc = b - c.k4;
+    da = c.k0 * bc - c.k1 * ac;
+    db = c.k0 * ac - c.k2 * bc;
+  }
+};
+
+// ---- Jeffrey   nfp.py:295-308 -------------------------------------------------------------------
+template <>
+struct Meas<NFP_JEFFREY> {
+  static constexpr int NSTAT = 0;
+  __device__ static __forceinline__ float term(float a, float b, const KP& g) {
+    float ca = fabsf(a) + g.eps, cb = fabsf(b) + g.eps;
+    return ca * logf(ca / cb) + cb * logf(cb / ca);
+  }
+  __device__ static __forceinline__ void stat(float, float&, float&) {}
+  __device__ static __forceinline__ float fin(float acc, float, float, float, float, const KP& g) {
+    return g.similarity ? -acc : acc;
+  }
+  __device__ static __forceinline__ Coef coef(float go, float, float, float, float, float, const KP& g) {
+    Coef c = {dist_sign(g, go), 0.f, 0.f, 0.f, 0.f};
+    return c;
+  }
+  __device__ static __forceinline__ void grad(float a, float b, const Coef& c, const KP& g, float& da, float& db) {
+    float ca = fabsf(a) + g.eps, cb = fabsf(b) + g.eps, l = logf(ca / cb);
+    da = c.k0 * (l + 1.f - cb / ca) * sgnf(a);
+    db = c.k0 * (-l + 1.f - ca / cb) * sgnf(b);
+  }
+};
+
+// ---- Smith   nfp.py:326-342 -----------------------------------------------------------------------
+template <>
+struct Meas<NFP_SMITH> {
+  static constexpr int NSTAT = 1;  // saved[0] = sum |a|
+  __device__ static __forceinline__ float term(float a, float b, const KP&) { return fminf(fabsf(a), fabsf(b)); }
+  __device__ static __forceinline__ void stat(float a, float& s0, float&) { s0 += fabsf(a); }
+  __device__ static __forceinline__ float fin(float acc, float sa0, float, float sb0, float, const KP& g) {
+    float f = 1.f - acc / (fminf(sa0, sb0) + g.eps);
+    return g.similarity ? f : -f;
+  }
+  __device__ static __forceinline__ float save0(float s0, float, const KP&) { return s0; }
+  __device__ static __forceinline__ float save1(float, float, const KP&) { return 0.f; }
+  __device__ static __forceinline__ Coef coef(float go, float outv, float sp, float, float sq, float, const KP& g) {
+    const float sg = g.similarity ? 1.f : -1.f;
+    const float mm = fminf(sp, sq) + g.eps, mn = (1.f - sg * outv) * mm;
+    const float wa = sp < sq ? 1.f : (sp == sq ? 0.5f : 0.f);
+    Coef c;
+    c.k0 = sg * go / mm;                       // * -t (tie-split indicator of the element-wise minimum)
+    c.k1 = sg * go * mn / (mm * mm) * wa;      // through min(sum|a|, sum|b|), centre side
+    c.k2 = sg * go * mn / (mm * mm) * (1.f - wa);
+    c.k3 = c.k4 = 0.f;
+    return c;
+  }
+  __device__ static __forceinline__ void grad(float a, float b, const Coef& c, const KP&, float& da, float& db) {
+    const float A = fabsf(a), B = fabsf(b);
+    const float ta = A < B ? 1.f : (A == B ? 0.5f : 0.f);
+    da = (-ta * c.k0 + c.k1) * sgnf(a);
+    db = (-(1.f - ta) * c.k0 + c.k2) * sgnf(b);
+  }
+};
+
+// ---- Attention   nfp.py:195-205: the dot products go through DotProduct's kernels; the softmax over
+// the N neighbours and its Jacobian are separate tiny kernels (nfp_generic.h).
+template <>
+struct Meas<NFP_ATTENTION> : Meas<NFP_DOT> {};
 
 }  // namespace nfp
