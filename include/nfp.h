@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define NFP_ABI_VERSION 1
+#define NFP_ABI_VERSION 2
 
 /* error codes */
 #define NFP_OK 0
@@ -104,6 +104,21 @@ int nfp_forward(const nfp_desc* d, const void* x, void* out, float* saved, void*
  *   grad_x   [B,C,H,W] with the strides of x; fully overwritten */
 int nfp_backward(const nfp_desc* d, const void* x, const void* grad_out, const void* out,
                  const float* saved, void* grad_x, void* hip_stream);
+
+/*
+ * Fused tail of models/NFP_Pooling.py:27-31 (the wrapper every live model uses): one pass over x yields
+ *   gap  [B,C] f32 = AdaptiveAvgPool2d(1)(x)                          NFP_Pooling.py:27
+ *   nfpm [B,N] f32 = adaptive_avg_pool2d(NFPPooling(x), 1)            NFP_Pooling.py:29-31
+ * out_map [B,N,Ho,Wo] (dtype of x) is also written: the backward needs it, callers may ignore it.
+ * Served only where nfp_pool_supported(d) != 0 (hot-path geometry, NCHW float32); otherwise compose
+ * nfp_forward with ordinary pooling.
+ */
+int nfp_pool_supported(const nfp_desc* d);
+int nfp_pool_forward(const nfp_desc* d, const void* x, float* gap, float* nfpm, void* out_map, float* saved,
+                     void* hip_stream);
+/* grad_x = d( sum(gap*grad_gap) + sum(nfpm*grad_nfpm) ) / dx;  out_map / saved from nfp_pool_forward. */
+int nfp_pool_backward(const nfp_desc* d, const void* x, const float* grad_gap, const float* grad_nfpm,
+                      const void* out_map, const float* saved, void* grad_x, void* hip_stream);
 
 /* Telemetry: kernels enqueued by this process so far (tests use it to prove
  * the HIP path, not a fallback, produced a result). */

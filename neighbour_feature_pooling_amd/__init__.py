@@ -3,11 +3,12 @@
 Drop-in for the reference's NFP hot path:
     NFPPooling, EnhancedNFPPooling   <- models/pooling/nfp.py::NFPPooling
     nfp_pooling                      <- models/NFP_Pooling.py::nfp_pooling
-    nfp, NfpConfig                   functional form (autograd op over libnfp_hip.so)
+    nfp_op, nfp_pool, NfpConfig      functional forms (autograd ops over libnfp_hip.so)
 """
-from .functional import NfpConfig, nfp
+from .functional import NfpConfig, nfp_pool
+from .functional import nfp as nfp_op  # (`nfp` itself is the submodule holding NFPPooling)
 from .nfp import EnhancedNFPPooling, NFPPooling
 from .pooling import nfp_pooling
 
-__all__ = ["NFPPooling", "EnhancedNFPPooling", "nfp_pooling", "nfp", "NfpConfig"]
+__all__ = ["NFPPooling", "EnhancedNFPPooling", "nfp_pooling", "nfp_op", "nfp_pool", "NfpConfig"]
 __version__ = "0.1.0"

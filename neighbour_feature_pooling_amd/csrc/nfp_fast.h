@@ -303,9 +303,16 @@ __device__ __forceinline__ float inv_norm(float n2, float inv_eps) {
 }
 
 // ---- forward --------------------------------------------------------------------------------
-template <int R, int M, bool BF, bool NHWC>
+// POOL = the fused tail of models/NFP_Pooling.py:27-31: besides the neighbour maps the same pass emits
+//   gap[b,c]  = mean over pixels of x[b,c]      (AdaptiveAvgPool2d(1), NFP_Pooling.py:27)
+//   nfpm[b,n] = mean over pixels of out[b,n]    (adaptive_avg_pool2d of the NFP maps, NFP_Pooling.py:31)
+// GAP comes from the 4x4 staging blocks while they are still in registers (4-pixel partial sums,
+// one extra ds_write_b128 per block, then 13 conflict-free reads per channel quad); NCHW f32 only.
+template <int R, int M, bool BF, bool NHWC, bool POOL = false>
 __global__ void __launch_bounds__(kFwdThreads) fwd_fast(const KP g, const void* __restrict__ x, void* __restrict__ out,
-                                                        float* __restrict__ saved) {
+                                                        float* __restrict__ saved, float* __restrict__ gap,
+                                                        float* __restrict__ nfpm) {
+  static_assert(!POOL || (!BF && !NHWC), "fused pooling tail: NCHW float32 only");
   constexpr int N = Win<R>::N, NF = Win<R>::NF;
   extern __shared__ __attribute__((aligned(16))) float4 lds4[];
   float4* slab = lds4;
@@ -342,12 +349,38 @@ __global__ void __launch_bounds__(kFwdThreads) fwd_fast(const KP g, const void* 
   for (int d = 0; d < NF; ++d) acc[d] = 0.f;
   float nrm = 0.f;
   const int Pp = (P + 3) & ~3, sp = swz(p);
+  const int NQ = P >> 2, PT = P & 3, NB = NQ + PT;  // GAP partials per channel quad
+  float4* gp = slab + (g.Cc >> 2) * Pp;             // [Cc/4][NB] (POOL only)
 
   for (int c0 = 0; c0 < g.C; c0 += g.Cc) {
     const int ncq = min(g.Cc, g.C - c0) >> 2;
     if (c0 > 0) {
       __syncthreads();  // previous chunk fully consumed
       stage_issue<BF, NHWC>(st, xb, g, c0, ncq, t, T, p, gl, active);
+    }
+    if constexpr (POOL) {
+      // 4-pixel (block) and 1-pixel (tail) partial channel sums, straight from the staged registers
+#pragma unroll
+      for (int r = 0; r < kRB; ++r) {
+        const int i = t + r * T;
+        if (i < ncq * NQ) {
+          const int cq = fast_div(i, g.invNQ), pq = i - cq * NQ;
+          float4 s4;
+          s4.x = (st.blk[r][0].x + st.blk[r][0].y) + (st.blk[r][0].z + st.blk[r][0].w);
+          s4.y = (st.blk[r][1].x + st.blk[r][1].y) + (st.blk[r][1].z + st.blk[r][1].w);
+          s4.z = (st.blk[r][2].x + st.blk[r][2].y) + (st.blk[r][2].z + st.blk[r][2].w);
+          s4.w = (st.blk[r][3].x + st.blk[r][3].y) + (st.blk[r][3].z + st.blk[r][3].w);
+          gp[cq * NB + pq] = s4;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < kRT; ++r) {
+        const int i = t + r * T;
+        if (i < ncq * PT) {
+          const int cq = fast_div(i, g.invPT), pt = i - cq * PT;
+          gp[cq * NB + NQ + pt] = st.tl[r];
+        }
+      }
     }
     int done = 0;
 #pragma unroll
@@ -382,6 +415,21 @@ __global__ void __launch_bounds__(kFwdThreads) fwd_fast(const KP g, const void* 
         }
       }
       done = upto;
+    }
+    if constexpr (POOL) {
+      // the commits' barriers have made gp visible; one thread per channel quad, fixed order
+      for (int cq = t; cq < ncq; cq += T) {
+        float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = 0; k < NB; ++k) {
+          const float4 v = gp[cq * NB + k];
+          s4.x += v.x;
+          s4.y += v.y;
+          s4.z += v.z;
+          s4.w += v.w;
+        }
+        const float ip_ = g.invP;
+        *(float4*)(gap + (long long)b * g.C + c0 + 4 * cq) = make_float4(s4.x * ip_, s4.y * ip_, s4.z * ip_, s4.w * ip_);
+      }
     }
   }
 #if NFP_ABLATE & 8
@@ -439,17 +487,35 @@ __global__ void __launch_bounds__(kFwdThreads) fwd_fast(const KP g, const void* 
         v = g.similarity ? -dd : dd;
       }
       stx(ob, n * P + p, v, BF ? NFP_BF16 : NFP_F32);
+      if constexpr (POOL) Tt[(NF + 1) * P + n * P + p] = v;  // vm[n][p], behind the half-stencil table
     }
     if (M == NFP_COSINE && saved != nullptr && gl == 0) saved[(long long)b * P + p] = __builtin_amdgcn_sqrtf(n2p);
+  }
+  if constexpr (POOL) {
+    __syncthreads();
+    // wave w reduces map n = w, w + nwaves, ...: lane-strided partial sums, then a fixed shuffle tree
+    const float* vm = Tt + (NF + 1) * P;
+    const int lane = t & 63, wv = t >> 6, nw = T >> 6;
+    for (int n = wv; n < N; n += nw) {
+      float sacc = 0.f;
+      for (int i = lane; i < P; i += 64) sacc += vm[n * P + i];
+      for (int m = 32; m >= 1; m >>= 1) sacc += __shfl_xor(sacc, m);
+      if (lane == 0) nfpm[(long long)b * N + n] = sacc * g.invP;
+    }
   }
   NFP_STAMP(5);
 }
 
 // ---- backward -------------------------------------------------------------------------------
-template <int R, int M, bool BF, bool NHWC>
+// POOL: grad_out is not a map but the gradients of the two pooled outputs: go[b,n,p] = gnfpm[b,n]/P
+// for every p, and every grad_x[b,c,p] also receives ggap[b,c]/P (adjoint of the two means).
+template <int R, int M, bool BF, bool NHWC, bool POOL = false>
 __global__ void __launch_bounds__(kBwdThreads) bwd_fast(const KP g, const void* __restrict__ x,
                                                         const void* __restrict__ go, const void* __restrict__ out,
-                                                        const float* __restrict__ saved, void* __restrict__ gx) {
+                                                        const float* __restrict__ saved, void* __restrict__ gx,
+                                                        const float* __restrict__ ggap,
+                                                        const float* __restrict__ gnfpm) {
+  static_assert(!POOL || (!BF && !NHWC), "fused pooling tail: NCHW float32 only");
   constexpr int K = Win<R>::K, K2 = Win<R>::K2, N = Win<R>::N;
   extern __shared__ __attribute__((aligned(16))) float4 lds4[];
   const int P = g.P;
@@ -493,7 +559,7 @@ __global__ void __launch_bounds__(kBwdThreads) bwd_fast(const KP g, const void* 
       const int n = min(n0 + u * g.G, N - 1);
       int qy, qx;
       a1.qn[u] = nm.get(g, n, qy, qx);
-      a1.gv[u] = ldx(gob, n * P + p, DT);
+      a1.gv[u] = POOL ? gnfpm[(long long)b * N + n] * g.invP : ldx(gob, n * P + p, DT);
       a1.ov[u] = ldx(outb, n * P + p, DT);
       a1.nqv[u] = (M == NFP_COSINE) ? svb[max(a1.qn[u], 0)] : 0.f;
     }
@@ -652,6 +718,10 @@ __global__ void __launch_bounds__(kBwdThreads) bwd_fast(const KP g, const void* 
       for (int cq = gl; cq < ncq; cq += g.G) {
         const float4* row = slab + cq * Pp + sp;
         float4 r4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (POOL) {
+          const float4 gg = *(const float4*)(ggap + (long long)b * g.C + c0 + 4 * cq);
+          r4 = make_float4(gg.x * g.invP, gg.y * g.invP, gg.z * g.invP, gg.w * g.invP);
+        }
 #pragma unroll
         for (int j = 0; j < K2; ++j) {
           const float4 q = row[off[j]];

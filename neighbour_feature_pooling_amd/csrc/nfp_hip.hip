@@ -209,8 +209,9 @@ int chunk_channels(const KP& g, int total, int T, int G, bool nhwc, int budget) 
   return round4((total + nch - 1) / nch);
 }
 
-template <int R, int M, bool BF, bool NHWC>
-int launch_fwd_fast_t(KP g, const void* x, void* out, float* saved, hipStream_t st) {
+template <int R, int M, bool BF, bool NHWC, bool POOL = false>
+int launch_fwd_fast_t(KP g, const void* x, void* out, float* saved, hipStream_t st, float* gap = nullptr,
+                      float* nfpm = nullptr) {
   constexpr int NF = Win<R>::NF;
   g.G = kFwdThreads / g.P;
   if (g.G < 1) g.G = 1;
@@ -220,19 +221,23 @@ int launch_fwd_fast_t(KP g, const void* x, void* out, float* saved, hipStream_t 
   // that, half-size slabs let two workgroups share a CU and overlap each other's phases (measured
   // +29 % at B = 1024, -16 % at B = 64).
   const int fbudget = g.B > 256 ? kSlabBudgetFwd / 2 : kSlabBudgetFwd;
-  g.Cc = chunk_channels(g, g.C, T, g.G, NHWC, fbudget);
+  // (the fused-pool variant also keeps (P/4 + P%4) partial-sum slots per channel quad)
+  const int fb = POOL ? (int)((long long)fbudget * g.P / (g.P + (g.P >> 2) + (g.P & 3) + 4)) : fbudget;
+  g.Cc = chunk_channels(g, g.C, T, g.G, NHWC, fb);
   g.G = even_groups(g.Cc / 4, g.G);
   T = ((g.P * g.G + 63) / 64) * 64;
-  g.Cc = chunk_channels(g, g.C, T, g.G, NHWC, fbudget);
+  g.Cc = chunk_channels(g, g.C, T, g.G, NHWC, fb);
   size_t slab = (size_t)(g.Cc / 4) * ((g.P + 3) & ~3) * 16;
+  if (POOL) slab += (size_t)(g.Cc / 4) * ((g.P >> 2) + (g.P & 3)) * 16;  // GAP partials
   size_t red = (size_t)(g.G + 1) * (NF + 1) * g.P * 4;
+  if (POOL) red += (size_t)Win<R>::N * g.P * 4;  // pooled-map staging
   size_t lds = slab > red ? slab : red;
   if (lds > (size_t)kLdsMax) return fail(NFP_E_UNSUPPORTED, "fwd_fast: LDS %zu", lds);
-  if (int rc = set_lds(fwd_fast<R, M, BF, NHWC>, lds)) return rc;
-  hipLaunchKernelGGL((fwd_fast<R, M, BF, NHWC>), dim3(g.B), dim3(T), lds, st, g, x, out, saved);
+  if (int rc = set_lds(fwd_fast<R, M, BF, NHWC, POOL>, lds)) return rc;
+  hipLaunchKernelGGL((fwd_fast<R, M, BF, NHWC, POOL>), dim3(g.B), dim3(T), lds, st, g, x, out, saved, gap, nfpm);
   g_launches++;
-  snprintf(g_variant, sizeof(g_variant), "fwd_fast<R%d,%s,%s,%s>", R, M == NFP_COSINE ? "cos" : "l2",
-           BF ? "bf16" : "f32", NHWC ? "nhwc" : "nchw");
+  snprintf(g_variant, sizeof(g_variant), "fwd_fast<R%d,%s,%s,%s%s>", R, M == NFP_COSINE ? "cos" : "l2",
+           BF ? "bf16" : "f32", NHWC ? "nhwc" : "nchw", POOL ? ",pool" : "");
   return hip_ok(hipGetLastError(), "launch fwd_fast");
 }
 
@@ -245,9 +250,9 @@ int launch_fwd_fast(const KP& g, const void* x, void* out, float* saved, hipStre
               : launch_fwd_fast_t<R, M, false, false>(g, x, out, saved, st);
 }
 
-template <int R, int M, bool BF, bool NHWC>
+template <int R, int M, bool BF, bool NHWC, bool POOL = false>
 int launch_bwd_fast_t(KP g, const void* x, const void* go, const void* out, const float* saved, void* gx,
-                      hipStream_t st) {
+                      hipStream_t st, const float* ggap = nullptr, const float* gnfpm = nullptr) {
   constexpr int N = Win<R>::N, K2 = Win<R>::K2;
 #ifndef NFP_BWD_WGS
 #define NFP_BWD_WGS 256
@@ -274,11 +279,12 @@ int launch_bwd_fast_t(KP g, const void* x, const void* go, const void* out, cons
   if (!NHWC && !NFP_DIRECT_STORE) xs = tables > 2 * slab ? tables : 2 * slab;  // + result slab of the LDS-transposed epilogue
   size_t lds = ((wt + 15) & ~(size_t)15) + xs;
   if (lds > (size_t)kLdsMax) return fail(NFP_E_UNSUPPORTED, "bwd_fast: LDS %zu", lds);
-  if (int rc = set_lds(bwd_fast<R, M, BF, NHWC>, lds)) return rc;
-  hipLaunchKernelGGL((bwd_fast<R, M, BF, NHWC>), dim3(g.B, S), dim3(T), lds, st, g, x, go, out, saved, gx);
+  if (int rc = set_lds(bwd_fast<R, M, BF, NHWC, POOL>, lds)) return rc;
+  hipLaunchKernelGGL((bwd_fast<R, M, BF, NHWC, POOL>), dim3(g.B, S), dim3(T), lds, st, g, x, go, out, saved, gx, ggap,
+                     gnfpm);
   g_launches++;
-  snprintf(g_variant, sizeof(g_variant), "bwd_fast<R%d,%s,%s,%s>", R, M == NFP_COSINE ? "cos" : "l2",
-           BF ? "bf16" : "f32", NHWC ? "nhwc" : "nchw");
+  snprintf(g_variant, sizeof(g_variant), "bwd_fast<R%d,%s,%s,%s%s>", R, M == NFP_COSINE ? "cos" : "l2",
+           BF ? "bf16" : "f32", NHWC ? "nhwc" : "nchw", POOL ? ",pool" : "");
   return hip_ok(hipGetLastError(), "launch bwd_fast");
 }
 
@@ -416,6 +422,45 @@ int nfp_backward(const nfp_desc* d, const void* x, const void* grad_out, const v
     default:
       return fail(NFP_E_UNSUPPORTED, "measure %d (SharpenedCosine) has no HIP kernel", g.measure);
   }
+}
+
+// ---- fused nfp_pooling tail (models/NFP_Pooling.py:27-31) ----------------------------------------------
+int nfp_pool_supported(const nfp_desc* d) {
+  KP g;
+  if (make_kp(d, &g)) return 0;
+  // hot-path geometry, NCHW float32 (x pointer alignment does not matter for NCHW)
+  return g.dtype == NFP_F32 && g.contig && fast_ok(g, nullptr, nullptr) ? 1 : 0;
+}
+
+int nfp_pool_forward(const nfp_desc* d, const void* x, float* gap, float* nfpm, void* out_map, float* saved,
+                     void* hip_stream) {
+  KP g;
+  if (int rc = make_kp(d, &g)) return rc;
+  if (!x || !gap || !nfpm || !out_map) return fail(NFP_E_INVALID, "null tensor pointer");
+  if (!nfp_pool_supported(d)) return fail(NFP_E_UNSUPPORTED, "fused pooling tail: hot-path geometry, NCHW float32 only");
+  if (g.B == 0) return NFP_OK;
+  hipStream_t st = (hipStream_t)hip_stream;
+  if (g.measure == NFP_COSINE)
+    return g.R == 1 ? launch_fwd_fast_t<1, NFP_COSINE, false, false, true>(g, x, out_map, saved, st, gap, nfpm)
+                    : launch_fwd_fast_t<2, NFP_COSINE, false, false, true>(g, x, out_map, saved, st, gap, nfpm);
+  return g.R == 1 ? launch_fwd_fast_t<1, NFP_NORM, false, false, true>(g, x, out_map, saved, st, gap, nfpm)
+                  : launch_fwd_fast_t<2, NFP_NORM, false, false, true>(g, x, out_map, saved, st, gap, nfpm);
+}
+
+int nfp_pool_backward(const nfp_desc* d, const void* x, const float* grad_gap, const float* grad_nfpm,
+                      const void* out_map, const float* saved, void* grad_x, void* hip_stream) {
+  KP g;
+  if (int rc = make_kp(d, &g)) return rc;
+  if (!x || !grad_gap || !grad_nfpm || !out_map || !grad_x) return fail(NFP_E_INVALID, "null tensor pointer");
+  if (!nfp_pool_supported(d)) return fail(NFP_E_UNSUPPORTED, "fused pooling tail: hot-path geometry, NCHW float32 only");
+  if (stats_of(g.measure) > 0 && !saved) return fail(NFP_E_INVALID, "missing saved state");
+  if (g.B == 0) return NFP_OK;
+  hipStream_t st = (hipStream_t)hip_stream;
+  if (g.measure == NFP_COSINE)
+    return g.R == 1 ? launch_bwd_fast_t<1, NFP_COSINE, false, false, true>(g, x, nullptr, out_map, saved, grad_x, st, grad_gap, grad_nfpm)
+                    : launch_bwd_fast_t<2, NFP_COSINE, false, false, true>(g, x, nullptr, out_map, saved, grad_x, st, grad_gap, grad_nfpm);
+  return g.R == 1 ? launch_bwd_fast_t<1, NFP_NORM, false, false, true>(g, x, nullptr, out_map, saved, grad_x, st, grad_gap, grad_nfpm)
+                  : launch_bwd_fast_t<2, NFP_NORM, false, false, true>(g, x, nullptr, out_map, saved, grad_x, st, grad_gap, grad_nfpm);
 }
 
 }  // extern "C"

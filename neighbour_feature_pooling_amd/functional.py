@@ -106,6 +106,59 @@ class _NfpHip(torch.autograd.Function):
         return gx, None
 
 
+class _NfpPoolHip(torch.autograd.Function):
+    """(gap [B,C], nfpm [B,N]) = fused tail of models/NFP_Pooling.py:27-31 in one pass over x."""
+
+    @staticmethod
+    def forward(ctx, x, cfg):
+        L = _abi.load()
+        x = x.contiguous()
+        d = make_desc(x, cfg)
+        with torch.cuda.device(x.device):
+            B, N, Ho, Wo = output_shape(d)
+            gap = torch.empty(B, x.shape[1], dtype=torch.float32, device=x.device)
+            nfpm = torch.empty(B, N, dtype=torch.float32, device=x.device)
+            out_map = torch.empty(B, N, Ho, Wo, dtype=x.dtype, device=x.device)
+            ns = L.nfp_saved_floats(ctypes.byref(d))
+            saved = torch.empty(max(ns, 0), dtype=torch.float32, device=x.device)
+            stream = torch.cuda.current_stream(x.device).cuda_stream
+            _abi.check(L.nfp_pool_forward(ctypes.byref(d), x.data_ptr(), gap.data_ptr(), nfpm.data_ptr(),
+                                          out_map.data_ptr(), saved.data_ptr() if ns > 0 else None, stream))
+        ctx.desc = d
+        ctx.save_for_backward(x, out_map, saved)
+        return gap, nfpm
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_gap, g_nfpm):
+        x, out_map, saved = ctx.saved_tensors
+        L = _abi.load()
+        g_gap = g_gap.contiguous().float()
+        g_nfpm = g_nfpm.contiguous().float()
+        with torch.cuda.device(x.device):
+            gx = torch.empty_like(x)
+            stream = torch.cuda.current_stream(x.device).cuda_stream
+            _abi.check(L.nfp_pool_backward(ctypes.byref(ctx.desc), x.data_ptr(), g_gap.data_ptr(), g_nfpm.data_ptr(),
+                                           out_map.data_ptr(), saved.data_ptr() if saved.numel() else None,
+                                           gx.data_ptr(), stream))
+        return gx, None
+
+
+def nfp_pool_fused_ok(x, cfg):
+    """True when the fused GAP + pooled-NFP kernels can serve this call (hot-path geometry, NCHW f32)."""
+    if not (x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and x.is_contiguous()):
+        return False
+    return bool(_abi.load().nfp_pool_supported(ctypes.byref(make_desc(x, cfg))))
+
+
+def nfp_pool(x, cfg):
+    """(GAP(x) [B,C], GAP(NFP(x)) [B,N]) — NFP_Pooling.py:27-31.  Fused on the GPU where supported,
+    otherwise the same two reductions composed from `nfp` and torch ops."""
+    if x.dim() == 4 and nfp_pool_fused_ok(x, cfg):
+        return _NfpPoolHip.apply(x, cfg)
+    return x.mean((2, 3)), nfp(x, cfg).mean((2, 3))
+
+
 def nfp(x, cfg):
     """[B,C,H,W] -> [B, k*k-1, H', W'] neighbour-similarity maps (NFPPooling.forward, nfp.py:132-134)."""
     if x.dim() != 4:

@@ -8,6 +8,7 @@ HIP-backed NFPPooling of this package.
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .functional import nfp_pool
 from .nfp import NFPPooling
 
 
@@ -31,8 +32,13 @@ class nfp_pooling(nn.Module):
         self.nfp_proj = nn.Linear(self.nfp_layer.out_channels, dense_feature_dim) if Params else None
 
     def forward(self, x):
-        x_avg = self.avgpool(x).flatten(1)                                   # NFP_Pooling.py:27
-        x_nfp = F.adaptive_avg_pool2d(self.nfp_layer(x), 1).flatten(1)       # NFP_Pooling.py:29-31
+        if isinstance(self.nfp_layer, NFPPooling) and x.dim() == 4 and x.shape[1] == self.nfp_layer.in_channels:
+            # both means come out of ONE pass over x on the GPU (nfp_pool_forward / nfp_pool_backward)
+            x_avg, x_nfp = nfp_pool(x, self.nfp_layer.config)
+            x_avg, x_nfp = x_avg.to(x.dtype), x_nfp.to(x.dtype)
+        else:
+            x_avg = self.avgpool(x).flatten(1)                               # NFP_Pooling.py:27
+            x_nfp = F.adaptive_avg_pool2d(self.nfp_layer(x), 1).flatten(1)   # NFP_Pooling.py:29-31
         if self.nfp_proj is not None:
             x_nfp = self.nfp_proj(x_nfp)                                     # NFP_Pooling.py:32-33
         return x_avg * x_nfp                                                 # NFP_Pooling.py:35
