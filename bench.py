@@ -151,11 +151,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    # NFP_BENCH_BACKEND=gloo rehearses the N>1 path with several ranks sharing one GPU (RCCL refuses that)
+    backend = os.environ.get("NFP_BENCH_BACKEND", "nccl")
+    local = local % torch.cuda.device_count() if backend == "gloo" else local
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    assert torch.cuda.is_available(), "bench.py needs a GPU"
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
@@ -222,7 +228,7 @@ def main():
         bwd_variant = L.nfp_last_variant().decode()
 
     from neighbour_feature_pooling_amd.parallel import max_over_ranks
-    elapsed = max_over_ranks(t1 - t0, device=dev)
+    elapsed = max_over_ranks(t1 - t0, device=dev if backend == "nccl" else "cpu")
     px_per_step = B * S * S
     value = world * px_per_step * args.steps / elapsed / 1e6
 
