@@ -71,18 +71,51 @@ def output_shape(d):
     return d.B, n.value, ho.value, wo.value
 
 
+_PLANS = {}
+
+
+def _plan(x, cfg):
+    """(descriptor, output shape, saved floats) for this input signature — cached: in eager mode the
+    host side of a call (a few ctypes round trips) otherwise costs more than the two kernels."""
+    key = (tuple(x.shape), x.stride(), x.dtype, cfg)
+    plan = _PLANS.get(key)
+    if plan is None:
+        L = _abi.load()
+        d = make_desc(x, cfg)
+        plan = (d, output_shape(d), int(L.nfp_saved_floats(ctypes.byref(d))))
+        if len(_PLANS) > 256:
+            _PLANS.clear()
+        _PLANS[key] = plan
+    return plan
+
+
+class _on_device:
+    """`with torch.cuda.device(dev)` only when dev is not already current (the common case costs nothing)."""
+
+    def __init__(self, dev):
+        self.ctx = None if dev.index == torch.cuda.current_device() else torch.cuda.device(dev)
+
+    def __enter__(self):
+        if self.ctx is not None:
+            self.ctx.__enter__()
+
+    def __exit__(self, *a):
+        if self.ctx is not None:
+            self.ctx.__exit__(*a)
+
+
 class _NfpHip(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, cfg):
         L = _abi.load()
         x = _dense(x)
-        d = make_desc(x, cfg)
-        need_grad = ctx.needs_input_grad[0]
-        with torch.cuda.device(x.device):
-            out = torch.empty(output_shape(d), dtype=x.dtype, device=x.device)
-            ns = L.nfp_saved_floats(ctypes.byref(d)) if need_grad else 0
+        d, oshape, ns = _plan(x, cfg)
+        if not ctx.needs_input_grad[0]:
+            ns = 0
+        with _on_device(x.device):
+            out = torch.empty(oshape, dtype=x.dtype, device=x.device)
             saved = torch.empty(max(ns, 0), dtype=torch.float32, device=x.device)
-            stream = torch.cuda.current_stream(x.device).cuda_stream
+            stream = torch.cuda.current_stream().cuda_stream
             _abi.check(L.nfp_forward(ctypes.byref(d), x.data_ptr(), out.data_ptr(),
                                      saved.data_ptr() if ns > 0 else None, stream))
         ctx.desc = d
@@ -98,9 +131,9 @@ class _NfpHip(torch.autograd.Function):
         go = grad_out.contiguous()
         if go.dtype != x.dtype:
             go = go.to(x.dtype)
-        with torch.cuda.device(x.device):
+        with _on_device(x.device):
             gx = torch.empty_like(x)  # same strides as x (dense NCHW or channels-last)
-            stream = torch.cuda.current_stream(x.device).cuda_stream
+            stream = torch.cuda.current_stream().cuda_stream
             _abi.check(L.nfp_backward(ctypes.byref(d), x.data_ptr(), go.data_ptr(), out.data_ptr(),
                                       saved.data_ptr() if saved.numel() else None, gx.data_ptr(), stream))
         return gx, None
@@ -113,15 +146,13 @@ class _NfpPoolHip(torch.autograd.Function):
     def forward(ctx, x, cfg):
         L = _abi.load()
         x = x.contiguous()
-        d = make_desc(x, cfg)
-        with torch.cuda.device(x.device):
-            B, N, Ho, Wo = output_shape(d)
+        d, (B, N, Ho, Wo), ns = _plan(x, cfg)
+        with _on_device(x.device):
             gap = torch.empty(B, x.shape[1], dtype=torch.float32, device=x.device)
             nfpm = torch.empty(B, N, dtype=torch.float32, device=x.device)
             out_map = torch.empty(B, N, Ho, Wo, dtype=x.dtype, device=x.device)
-            ns = L.nfp_saved_floats(ctypes.byref(d))
             saved = torch.empty(max(ns, 0), dtype=torch.float32, device=x.device)
-            stream = torch.cuda.current_stream(x.device).cuda_stream
+            stream = torch.cuda.current_stream().cuda_stream
             _abi.check(L.nfp_pool_forward(ctypes.byref(d), x.data_ptr(), gap.data_ptr(), nfpm.data_ptr(),
                                           out_map.data_ptr(), saved.data_ptr() if ns > 0 else None, stream))
         ctx.desc = d
@@ -135,9 +166,9 @@ class _NfpPoolHip(torch.autograd.Function):
         L = _abi.load()
         g_gap = g_gap.contiguous().float()
         g_nfpm = g_nfpm.contiguous().float()
-        with torch.cuda.device(x.device):
+        with _on_device(x.device):
             gx = torch.empty_like(x)
-            stream = torch.cuda.current_stream(x.device).cuda_stream
+            stream = torch.cuda.current_stream().cuda_stream
             _abi.check(L.nfp_pool_backward(ctypes.byref(ctx.desc), x.data_ptr(), g_gap.data_ptr(), g_nfpm.data_ptr(),
                                            out_map.data_ptr(), saved.data_ptr() if saved.numel() else None,
                                            gx.data_ptr(), stream))
@@ -148,7 +179,11 @@ def nfp_pool_fused_ok(x, cfg):
     """True when the fused GAP + pooled-NFP kernels can serve this call (hot-path geometry, NCHW f32)."""
     if not (x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and x.is_contiguous()):
         return False
-    return bool(_abi.load().nfp_pool_supported(ctypes.byref(make_desc(x, cfg))))
+    key = ("pool", tuple(x.shape), cfg)
+    ok = _PLANS.get(key)
+    if ok is None:
+        ok = _PLANS[key] = bool(_abi.load().nfp_pool_supported(ctypes.byref(make_desc(x, cfg))))
+    return ok
 
 
 def nfp_pool(x, cfg):

@@ -48,6 +48,18 @@ class NFPPooling(nn.Module):
     # -- the op ------------------------------------------------------------------------------
     @property
     def config(self):
+        """Frozen view of the op-defining attributes (they are plain, assignable attributes as in the
+        reference, so the view is rebuilt only when one of them changed)."""
+        sig = (self.R, self.measure, self.p, self.stride, self.padding, self.dilation, self.padding_mode,
+               self.similarity, self.eps, self.q_scs, self._diff_weights)
+        cached = self.__dict__.get("_cfg_cache")
+        if cached is not None and cached[0] == sig:
+            return cached[1]
+        cfg = self._build_config()
+        self.__dict__["_cfg_cache"] = (sig, cfg)
+        return cfg
+
+    def _build_config(self):
         return NfpConfig(R=int(self.R), measure=_abi.MEASURE_ALIASES.get(self.measure, self.measure),
                          p=self.p, stride=int(self.stride), padding=int(self.padding),
                          dilation=int(self.dilation), padding_mode=self.padding_mode,
