@@ -118,6 +118,7 @@ int launch_fwd_generic(KP g, const void* x, void* out, float* saved, hipStream_t
   }
   int T = ((g.Ow * g.G + 63) / 64) * 64;
   size_t lds = (size_t)g.Cc * g.P * 4;
+  if (lds > (size_t)kLdsMax) return fail(NFP_E_UNSUPPORTED, "forward: feature map %dx%d does not fit LDS", g.H, g.W);
   if (int rc = set_lds(fwd_generic<M>, lds)) return rc;
   dim3 grid(g.B, (g.O + g.Ow - 1) / g.Ow, (g.N + kGroup - 1) / kGroup);
   hipLaunchKernelGGL(fwd_generic<M>, grid, dim3(T), lds, st, g, x, out, saved);
@@ -146,6 +147,9 @@ int launch_bwd_generic(KP g, const void* x, const void* go, const void* out, con
   if (g.Tc > g.Cc) g.Tc = g.Cc;
   int T = ((g.Ow * g.Tc + 63) / 64) * 64;
   size_t lds = ((size_t)((g.Cc * g.P + 3) & ~3) + (size_t)g.Cc * g.P) * 4;
+  if (lds > (size_t)kLdsMax)
+    return fail(NFP_E_UNSUPPORTED, "backward: feature map %dx%d needs %zu B of LDS for one channel (x + grad slabs), "
+                "limit %d", g.H, g.W, lds, kLdsMax);
   if (int rc = set_lds(bwd_generic<M>, lds)) return rc;
   dim3 grid(g.B, (g.C + g.Cwg - 1) / g.Cwg);
   hipLaunchKernelGGL(bwd_generic<M>, grid, dim3(T), lds, st, g, x, go, out, saved, gx);
