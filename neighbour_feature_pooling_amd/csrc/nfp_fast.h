@@ -46,15 +46,6 @@ namespace nfp {
 #ifndef NFP_UNROLL_F
 #define NFP_UNROLL_F 1
 #endif
-#ifndef NFP_STORE_MODE
-#define NFP_STORE_MODE 0  // grad_x stores: 0 plain, 1 nontemporal, 2 agent-scope (sc1, write-through)
-#endif
-#ifndef NFP_DIRECT_STORE
-#define NFP_DIRECT_STORE 1  // dword write-through stores straight from the compute loop (measured faster than the LDS-transposed 16-byte epilogue)
-#endif
-#ifndef NFP_A1_BARRIER
-#define NFP_A1_BARRIER 0
-#endif
 #ifndef NFP_UNROLL_B
 #define NFP_UNROLL_B 1
 #endif
@@ -132,10 +123,7 @@ __device__ __forceinline__ int fast_div(int i, float inv_d) { return (int)(((flo
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 using Rsrc = __amdgpu_buffer_rsrc_t;
-#ifndef NFP_STORE_AUX
-#define NFP_STORE_AUX 16  // 16 = sc1 (write-through), 0 = plain, 2 = nt
-#endif
-constexpr int kAuxSc1 = NFP_STORE_AUX;
+constexpr int kAuxSc1 = 16;  // buffer-store cache policy: sc1 = write-through
 __device__ __forceinline__ Rsrc make_rsrc(const void* base, long long bytes) {
   return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)(bytes > 0x7ffffff0LL ? 0x7ffffff0LL : bytes), 0x00020000);
 }
@@ -608,12 +596,6 @@ __global__ void __launch_bounds__(kBwdThreads) bwd_fast(const KP g, const void* 
   a1_load(gl);
 #endif
   __builtin_amdgcn_sched_barrier(0);  // keep these (small, needed first) loads ahead of the x chunk
-#if NFP_A1_BARRIER
-  // raw s_barrier (no waitcnt): every wave's coefficient loads enter the CU's memory queue before
-  // ANY wave's x loads, otherwise they queue behind the other waves' 16-byte loads
-  __builtin_amdgcn_s_barrier();
-  __builtin_amdgcn_sched_barrier(0);
-#endif
   Staged<NHWC> st;
 #if NFP_ABLATE & 64
   __builtin_memset(&st, 0, sizeof(st));
@@ -696,11 +678,11 @@ __global__ void __launch_bounds__(kBwdThreads) bwd_fast(const KP g, const void* 
     off[j] = ok ? swz(p + dy * g.W + dx) - swz(p) : 0;
     w[j] = (NFP_ABLATE & 16) ? 0.1f * j : (ok ? Wt[p * K2 + j] : 0.f);
   }
-  // B: one pass over the channel block.  NCHW: results go to a second LDS slab and leave as 4x4
-  // blocks (four 16-byte write-through stores along the pixel axis); channels-last: one 16-byte
-  // write-through store per slot straight from registers.
+  // B: one pass over the channel block; results leave straight from registers with write-through
+  // (sc1) stores — 4 dwords per slot for NCHW, one 16-byte store for channels-last — so grad_x
+  // streams out of L2 during the kernel instead of in its end-of-kernel flush (measured -0.45 us;
+  // an LDS-transposed 16-byte NCHW epilogue was 1.6 us slower).
   const int Pp = (P + 3) & ~3, sp = swz(p);
-  float4* oslab = slab + (g.Cc >> 2) * Pp;
   for (int c0 = cb0; c0 < cb1; c0 += g.Cc) {
     const int ncq = min(g.Cc, cb1 - c0) >> 2;
     if (c0 > cb0) {
@@ -736,42 +718,13 @@ __global__ void __launch_bounds__(kBwdThreads) bwd_fast(const KP g, const void* 
         if constexpr (NHWC) {
           store_px4<BF>(gxb, p * g.C + c0 + 4 * cq, 0, r4);
         } else {
-#if NFP_DIRECT_STORE
-          const int e = (c0 + 4 * cq) * P + p;
+          const int e = (c0 + 4 * cq) * P + p;  // one address VGPR, channel rows through the SGPR offset
           store_1<BF>(gxb, e, 0, r4.x);
           store_1<BF>(gxb, e, P, r4.y);
           store_1<BF>(gxb, e, 2 * P, r4.z);
           store_1<BF>(gxb, e, 3 * P, r4.w);
-#else
-          oslab[cq * Pp + sp] = r4;
-#endif
         }
 #endif
-      }
-    }
-    if constexpr (!NHWC && !NFP_DIRECT_STORE) {
-      __syncthreads();
-      const int NQ = P >> 2, PT = P & 3;
-      const int nblk = ncq * NQ, ntl = ncq * PT;
-      for (int i = t; i < nblk; i += T) {
-        const int cq = fast_div(i, g.invNQ), pq = i - cq * NQ;
-        const float4* d = oslab + cq * Pp + 4 * pq;
-        const int rot = (pq >> 1) & 3;
-        const float4 a0 = d[rot], a1 = d[(rot + 1) & 3], a2 = d[(rot + 2) & 3], a3 = d[(rot + 3) & 3];
-        const int e = (c0 + 4 * cq) * P + 4 * pq;
-        store_px4<BF>(gxb, e, 0, make_float4(a0.x, a1.x, a2.x, a3.x));
-        store_px4<BF>(gxb, e, P, make_float4(a0.y, a1.y, a2.y, a3.y));
-        store_px4<BF>(gxb, e, 2 * P, make_float4(a0.z, a1.z, a2.z, a3.z));
-        store_px4<BF>(gxb, e, 3 * P, make_float4(a0.w, a1.w, a2.w, a3.w));
-      }
-      for (int i = t; i < ntl; i += T) {
-        const int cq = fast_div(i, g.invPT), pt = i - cq * PT;
-        const float4 a = oslab[cq * Pp + swz(4 * NQ + pt)];
-        const int e = (c0 + 4 * cq) * P + 4 * NQ + pt;
-        store_1<BF>(gxb, e, 0, a.x);
-        store_1<BF>(gxb, e, P, a.y);
-        store_1<BF>(gxb, e, 2 * P, a.z);
-        store_1<BF>(gxb, e, 3 * P, a.w);
       }
     }
   }

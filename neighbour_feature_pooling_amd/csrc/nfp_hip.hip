@@ -280,7 +280,6 @@ int launch_bwd_fast_t(KP g, const void* x, const void* go, const void* out, cons
   size_t tables = (size_t)(4 * g.P * N + g.P * K2) * 4;
   size_t slab = (size_t)(g.Cc / 4) * ((g.P + 3) & ~3) * 16;
   size_t xs = slab > tables ? slab : tables;
-  if (!NHWC && !NFP_DIRECT_STORE) xs = tables > 2 * slab ? tables : 2 * slab;  // + result slab of the LDS-transposed epilogue
   size_t lds = ((wt + 15) & ~(size_t)15) + xs;
   if (lds > (size_t)kLdsMax) return fail(NFP_E_UNSUPPORTED, "bwd_fast: LDS %zu", lds);
   if (int rc = set_lds(bwd_fast<R, M, BF, NHWC, POOL>, lds)) return rc;

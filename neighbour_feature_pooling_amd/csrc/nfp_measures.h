@@ -25,7 +25,6 @@ struct Meas;
 template <>
 struct Meas<NFP_NORM> {
   static constexpr int NSTAT = 0;
-  static constexpr bool kLinear = false;  // linear in x only for p == 2 (fast path checks p)
   __device__ static __forceinline__ float term(float a, float b, const KP& g) {
     float v = g.diff ? a - b : b;
     if (g.p == 2.f) return v * v;
@@ -70,7 +69,6 @@ struct Meas<NFP_NORM> {
 template <>
 struct Meas<NFP_COSINE> {
   static constexpr int NSTAT = 1;  // saved[0] = |a|
-  static constexpr bool kLinear = true;
   __device__ static __forceinline__ float term(float a, float b, const KP&) { return a * b; }
   __device__ static __forceinline__ void stat(float a, float& s0, float&) { s0 = fmaf(a, a, s0); }
   __device__ static __forceinline__ float fin(float acc, float sa0, float, float sb0, float, const KP& g) {
