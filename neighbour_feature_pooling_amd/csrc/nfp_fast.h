@@ -51,7 +51,7 @@ namespace nfp {
 #endif
 constexpr int kRB = NFP_RB;  // NCHW staging: 4x4 blocks per thread per chunk
 constexpr int kRT = 2;    // NCHW staging: tail (P % 4) pixel slots per thread per chunk
-constexpr int kRN = 8;    // channels-last staging: slots per thread per chunk
+constexpr int kRN = 4;    // channels-last staging: slots per thread per chunk
 constexpr int kFwdThreads = NFP_FWD_THREADS;  // every instruction costs (waves per SIMD) x 2 clk of CU issue time
 constexpr int kBwdThreads = NFP_BWD_THREADS;  // backward keeps (2R+1)^2 weights + offsets + staged x in registers
 
@@ -296,8 +296,10 @@ __device__ __forceinline__ float inv_norm(float n2, float inv_eps) {
 //   nfpm[b,n] = mean over pixels of out[b,n]    (adaptive_avg_pool2d of the NFP maps, NFP_Pooling.py:31)
 // GAP comes from the 4x4 staging blocks while they are still in registers (4-pixel partial sums,
 // one extra ds_write_b128 per block, then 13 conflict-free reads per channel quad); NCHW f32 only.
-template <int R, int M, bool BF, bool NHWC, bool POOL = false>
-__global__ void __launch_bounds__(kFwdThreads) fwd_fast(const KP g, const void* __restrict__ x, void* __restrict__ out,
+// MAXT = workgroup size bound: 512 (2 waves/SIMD, the measured best for small maps) or 1024 for maps
+// with more than 128 pixels, where 512 threads would leave only 2-3 channel groups per image.
+template <int R, int M, bool BF, bool NHWC, bool POOL = false, int MAXT = kFwdThreads>
+__global__ void __launch_bounds__(MAXT) fwd_fast(const KP g, const void* __restrict__ x, void* __restrict__ out,
                                                         float* __restrict__ saved, float* __restrict__ gap,
                                                         float* __restrict__ nfpm) {
   static_assert(!POOL || (!BF && !NHWC), "fused pooling tail: NCHW float32 only");
@@ -615,60 +617,127 @@ __global__ void __launch_bounds__(kBwdThreads) bwd_fast(const KP g, const void* 
 #endif
   __syncthreads();
   NFP_STAMP(2);
-  // A2: gather.  Thread (r = p, slot j = gl, gl+G, ...), t = r + delta_j if inside the image.
-  if (active && !(NFP_ABLATE & 16)) {
-    for (int j = gl; j < K2; j += g.G) {
-      const int jy = j / K, jx = j - jy * K;
-      const int ty = py + jy - R, tx = px + jx - R;
-      float w = 0.f, s2 = 0.f;
-      if (ty >= 0 && ty < g.H && tx >= 0 && tx < g.W) {
-        const int tt = ty * g.W + tx;
-        const int4* qa = (const int4*)(Qt + p * N);
-        const float4* ca = (const float4*)(CR + p * N);
-        const int4* qb = (const int4*)(Qt + tt * N);
-        const float4* cb = (const float4*)(CR + tt * N);
-        const float4* sb = (const float4*)(SQ + tt * N);
-#pragma unroll
-        for (int m = 0; m < N / 4; ++m) {  // r as centre, tt as its neighbour
-          const int4 qq = qa[m];
-          const float4 cc = ca[m];
-          w += (qq.x == tt ? cc.x : 0.f) + (qq.y == tt ? cc.y : 0.f) + (qq.z == tt ? cc.z : 0.f) +
-               (qq.w == tt ? cc.w : 0.f);
-        }
-#pragma unroll
-        for (int m = 0; m < N / 4; ++m) {  // tt as centre, r as its neighbour
-          const int4 qq = qb[m];
-          const float4 cc = cb[m];
-          const float4 ss = sb[m];
-          w += (qq.x == p ? cc.x : 0.f) + (qq.y == p ? cc.y : 0.f) + (qq.z == p ? cc.z : 0.f) +
-               (qq.w == p ? cc.w : 0.f);
-          s2 += (qq.x == p ? ss.x : 0.f) + (qq.y == p ? ss.y : 0.f) + (qq.z == p ? ss.z : 0.f) +
-                (qq.w == p ? ss.w : 0.f);
-        }
-        if (tt == p) {
-          const float4* sa = (const float4*)(SP + p * N);
-#pragma unroll
-          for (int m = 0; m < N / 4; ++m) {
-            const float4 ss = sa[m];
-            w += (ss.x + ss.y) + (ss.z + ss.w);
+  if constexpr (R == 1) {
+    // A2: gather.  Thread (r = p, slot j = gl, gl+G, ...), t = r + delta_j if inside the image.
+    if (active && !(NFP_ABLATE & 16)) {
+      for (int j = gl; j < K2; j += g.G) {
+        const int jy = j / K, jx = j - jy * K;
+        const int ty = py + jy - R, tx = px + jx - R;
+        float w = 0.f, s2 = 0.f;
+        if (ty >= 0 && ty < g.H && tx >= 0 && tx < g.W) {
+          const int tt = ty * g.W + tx;
+          const int4* qa = (const int4*)(Qt + p * N);
+          const float4* ca = (const float4*)(CR + p * N);
+          const int4* qb = (const int4*)(Qt + tt * N);
+          const float4* cb = (const float4*)(CR + tt * N);
+          const float4* sb = (const float4*)(SQ + tt * N);
+  #pragma unroll
+          for (int m = 0; m < N / 4; ++m) {  // r as centre, tt as its neighbour
+            const int4 qq = qa[m];
+            const float4 cc = ca[m];
+            w += (qq.x == tt ? cc.x : 0.f) + (qq.y == tt ? cc.y : 0.f) + (qq.z == tt ? cc.z : 0.f) +
+                 (qq.w == tt ? cc.w : 0.f);
+          }
+  #pragma unroll
+          for (int m = 0; m < N / 4; ++m) {  // tt as centre, r as its neighbour
+            const int4 qq = qb[m];
+            const float4 cc = cb[m];
+            const float4 ss = sb[m];
+            w += (qq.x == p ? cc.x : 0.f) + (qq.y == p ? cc.y : 0.f) + (qq.z == p ? cc.z : 0.f) +
+                 (qq.w == p ? cc.w : 0.f);
+            s2 += (qq.x == p ? ss.x : 0.f) + (qq.y == p ? ss.y : 0.f) + (qq.z == p ? ss.z : 0.f) +
+                  (qq.w == p ? ss.w : 0.f);
+          }
+          if (tt == p) {
+            const float4* sa = (const float4*)(SP + p * N);
+  #pragma unroll
+            for (int m = 0; m < N / 4; ++m) {
+              const float4 ss = sa[m];
+              w += (ss.x + ss.y) + (ss.z + ss.w);
+            }
           }
         }
+        Wt[p * K2 + j] = w;
+        Sq2[p * K2 + j] = s2;
       }
-      Wt[p * K2 + j] = w;
-      Sq2[p * K2 + j] = s2;
     }
-  }
-  __syncthreads();
-  NFP_STAMP(3);
-  // A3: fold the neighbour-role self terms into the diagonal, fixed order
-  if (gl == 0 && !(NFP_ABLATE & 16)) {
-    float s = Wt[p * K2 + K2 / 2];
+    __syncthreads();
+    NFP_STAMP(3);
+    // A3: fold the neighbour-role self terms into the diagonal, fixed order
+    if (gl == 0 && !(NFP_ABLATE & 16)) {
+      float s = Wt[p * K2 + K2 / 2];
+  #pragma unroll
+      for (int j = 0; j < K2; ++j) s += Sq2[p * K2 + j];
+      Wt[p * K2 + K2 / 2] = s;
+    }
+    __syncthreads();
+    NFP_STAMP(4);
+  } else {
+    // Larger windows: the two-sided gather above costs 2N compares per table entry.  Instead bin each
+    // centre's own pairs by window slot — Out[r][j] = sum_{n: q(r,n) = r + delta_j} cross(r,n), same for the
+    // neighbour-self terms — and note that the pairs in which r is t's neighbour are exactly t's bin
+    // pointing back at r:  W[r][j] = Out[r][j] + Out[t][K2-1-j].  Every entry is still summed by one thread
+    // in a fixed order.
+    float* Out = Sq2 + P * K2;  // [P][K2]
+    float* Osq = Out + P * K2;  // [P][K2]
+    float* SPs = Osq + P * K2;  // [P]
+    if (active && !(NFP_ABLATE & 16)) {
+      for (int j = gl; j < K2; j += g.G) {
+        const int jy = j / K, jx = j - jy * K;
+        const int ty = py + jy - R, tx = px + jx - R;
+        const bool inside = ty >= 0 && ty < g.H && tx >= 0 && tx < g.W;
+        const int tt = inside ? ty * g.W + tx : -2;
+        const int4* qa = (const int4*)(Qt + p * N);
+        const float4* ca = (const float4*)(CR + p * N);
+        const float4* sa = (const float4*)(SQ + p * N);
+        float o = 0.f, q2 = 0.f;
 #pragma unroll
-    for (int j = 0; j < K2; ++j) s += Sq2[p * K2 + j];
-    Wt[p * K2 + K2 / 2] = s;
+        for (int m = 0; m < N / 4; ++m) {
+          const int4 qq = qa[m];
+          const float4 cc = ca[m], ss = sa[m];
+          o += (qq.x == tt ? cc.x : 0.f) + (qq.y == tt ? cc.y : 0.f) + (qq.z == tt ? cc.z : 0.f) +
+               (qq.w == tt ? cc.w : 0.f);
+          q2 += (qq.x == tt ? ss.x : 0.f) + (qq.y == tt ? ss.y : 0.f) + (qq.z == tt ? ss.z : 0.f) +
+                (qq.w == tt ? ss.w : 0.f);
+        }
+        Out[p * K2 + j] = o;
+        Osq[p * K2 + j] = q2;
+        if (j == K2 / 2) {
+          const float4* pa = (const float4*)(SP + p * N);
+          float sps = 0.f;
+#pragma unroll
+          for (int m = 0; m < N / 4; ++m) {
+            const float4 v4 = pa[m];
+            sps += (v4.x + v4.y) + (v4.z + v4.w);
+          }
+          SPs[p] = sps;
+        }
+      }
+    }
+    __syncthreads();
+    NFP_STAMP(3);
+    if (active && !(NFP_ABLATE & 16)) {
+      for (int j = gl; j < K2; j += g.G) {
+        const int jy = j / K, jx = j - jy * K;
+        const int ty = py + jy - R, tx = px + jx - R;
+        float wv = 0.f;
+        if (ty >= 0 && ty < g.H && tx >= 0 && tx < g.W) {
+          wv = Out[p * K2 + j] + Out[(ty * g.W + tx) * K2 + (K2 - 1 - j)];
+          if (j == K2 / 2) {
+            wv += SPs[p];
+#pragma unroll
+            for (int jj = 0; jj < K2; ++jj) {
+              const int uy = py + jj / K - R, ux = px + jj % K - R;
+              if (uy >= 0 && uy < g.H && ux >= 0 && ux < g.W) wv += Osq[(uy * g.W + ux) * K2 + (K2 - 1 - jj)];
+            }
+          }
+        }
+        Wt[p * K2 + j] = wv;
+      }
+    }
+    __syncthreads();
+    NFP_STAMP(4);
   }
-  __syncthreads();
-  NFP_STAMP(4);
   float w[K2];
   int off[K2];
 #pragma unroll

@@ -213,11 +213,13 @@ int chunk_channels(const KP& g, int total, int T, int G, bool nhwc, int budget) 
   return round4((total + nch - 1) / nch);
 }
 
-template <int R, int M, bool BF, bool NHWC, bool POOL = false>
+template <int R, int M, bool BF, bool NHWC, bool POOL = false, int MAXT = kFwdThreads>
 int launch_fwd_fast_t(KP g, const void* x, void* out, float* saved, hipStream_t st, float* gap = nullptr,
                       float* nfpm = nullptr) {
   constexpr int NF = Win<R>::NF;
-  g.G = kFwdThreads / g.P;
+  if (MAXT == kFwdThreads && !POOL && g.P > 128)  // big maps: 1024-thread variant (more channel groups per image)
+    return launch_fwd_fast_t<R, M, BF, NHWC, false, 1024>(g, x, out, saved, st, gap, nfpm);
+  g.G = MAXT / g.P;
   if (g.G < 1) g.G = 1;
   if (g.G > g.C / 4) g.G = g.C / 4;
   int T = ((g.P * g.G + 63) / 64) * 64;
@@ -237,8 +239,8 @@ int launch_fwd_fast_t(KP g, const void* x, void* out, float* saved, hipStream_t 
   if (POOL) red += (size_t)Win<R>::N * g.P * 4;  // pooled-map staging
   size_t lds = slab > red ? slab : red;
   if (lds > (size_t)kLdsMax) return fail(NFP_E_UNSUPPORTED, "fwd_fast: LDS %zu", lds);
-  if (int rc = set_lds(fwd_fast<R, M, BF, NHWC, POOL>, lds)) return rc;
-  hipLaunchKernelGGL((fwd_fast<R, M, BF, NHWC, POOL>), dim3(g.B), dim3(T), lds, st, g, x, out, saved, gap, nfpm);
+  if (int rc = set_lds(fwd_fast<R, M, BF, NHWC, POOL, MAXT>, lds)) return rc;
+  hipLaunchKernelGGL((fwd_fast<R, M, BF, NHWC, POOL, MAXT>), dim3(g.B), dim3(T), lds, st, g, x, out, saved, gap, nfpm);
   g_launches++;
   snprintf(g_variant, sizeof(g_variant), "fwd_fast<R%d,%s,%s,%s%s>", R, M == NFP_COSINE ? "cos" : "l2",
            BF ? "bf16" : "f32", NHWC ? "nhwc" : "nchw", POOL ? ",pool" : "");
@@ -277,7 +279,7 @@ int launch_bwd_fast_t(KP g, const void* x, const void* go, const void* out, cons
   T = ((g.P * g.G + 63) / 64) * 64;
   g.Cc = chunk_channels(g, g.Cwg, T, g.G, NHWC, bbudget);
   size_t wt = (size_t)g.P * K2 * 4;
-  size_t tables = (size_t)(4 * g.P * N + g.P * K2) * 4;
+  size_t tables = (size_t)(4 * g.P * N + g.P * K2 + (R >= 2 ? 2 * g.P * K2 + g.P : 0)) * 4;  // Qt CR SP SQ Sq2 [Out Osq SPs]
   size_t slab = (size_t)(g.Cc / 4) * ((g.P + 3) & ~3) * 16;
   size_t xs = slab > tables ? slab : tables;
   size_t lds = ((wt + 15) & ~(size_t)15) + xs;
