@@ -362,3 +362,46 @@ def test_nfp_pooling_wrapper_on_gpu_matches_reference_golden(dev):
     assert rel_err(y.detach().cpu().numpy(), g["y"]) <= 1e-5
     assert rel_err(x.grad.cpu().numpy(), g["gx"]) <= 1e-5
     assert rel_err(w.nfp_proj.weight.grad.cpu().numpy(), g["gw"]) <= 1e-5
+
+
+# ---- the C ABI called directly: raw device pointers + descriptor, no nn.Module / autograd in between ----
+
+@pytest.mark.parametrize("name", ["c1_cos_k3_2x64x14x14", "c2_cos_k3_4x512x7x7", "c5_l2_k5_4x192x14x14",
+                                  "geo_cos_stride2_dil2_pad0", "m_canberra", "m_pearson"])
+def test_c_abi_direct_calls_match_reference_golden(name, dev):
+    import ctypes
+    from neighbour_feature_pooling_amd import _abi
+    L = _abi.load()
+    c = K.BY_NAME[name]
+    g = load_golden(name)
+    ctor = dict(R=1, measure="norm", p=1, stride=1, padding=0, dilation=1, padding_mode="reflect", similarity=True,
+                eps=1e-6, q_scs=1e-6)
+    ctor.update(c["ctor"])
+    x = torch.from_numpy(K.make_input(c)).to(dev)
+    d = _abi.NfpDesc()
+    d.B, d.C, d.H, d.W = x.shape
+    d.R, d.pad, d.stride, d.dilation = ctor["R"], ctor["padding"], ctor["stride"], ctor["dilation"]
+    d.pad_mode = _abi.PAD_MODES.index(ctor["padding_mode"])
+    d.measure = _abi.measure_id(ctor["measure"].lower())
+    d.similarity = int(ctor["similarity"])
+    d.diff_weights = int(ctor["measure"] in ("norm", "rmse", "mahalanobis"))
+    d.dtype = _abi.F32
+    d.p, d.eps, d.q_scs = ctor["p"], ctor["eps"], ctor["q_scs"]
+    d.sxB, d.sxC, d.sxH, d.sxW = x.stride()
+    n, ho, wo = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+    assert L.nfp_output_shape(ctypes.byref(d), ctypes.byref(n), ctypes.byref(ho), ctypes.byref(wo)) == 0
+    assert (d.B, n.value, ho.value, wo.value) == g["out"].shape
+    out = torch.empty(g["out"].shape, device=dev)
+    saved = torch.empty(max(int(L.nfp_saved_floats(ctypes.byref(d))), 1), device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    assert L.nfp_forward(ctypes.byref(d), x.data_ptr(), out.data_ptr(), saved.data_ptr(), stream) == 0, L.nfp_last_error()
+    go = torch.from_numpy(K.make_grad_out(c, g["out"].shape)).to(dev)
+    gx = torch.empty_like(x)
+    assert L.nfp_backward(ctypes.byref(d), x.data_ptr(), go.data_ptr(), out.data_ptr(), saved.data_ptr(), gx.data_ptr(),
+                          stream) == 0, L.nfp_last_error()
+    torch.cuda.synchronize()
+    assert rel_err(out.cpu().numpy(), g["out"]) <= TOL
+    if "gx" in g:
+        assert rel_err(gx.cpu().numpy(), g["gx"]) <= TOL
+    else:
+        assert rel_err(gx.cpu().numpy().reshape(-1)[K.gx_sample_index(gx.numel())], g["gx_sample"]) <= TOL
