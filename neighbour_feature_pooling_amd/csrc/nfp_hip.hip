@@ -39,6 +39,7 @@ int hip_ok(hipError_t e, const char* what) {
 constexpr int kLdsBudgetFwd = 64 * 1024;  // bytes of x chunk per forward workgroup
 constexpr int kLdsBudgetBwd = 48 * 1024;  // bytes of x chunk (and as much again of grad) per backward workgroup
 constexpr int kLdsMax = 160 * 1024;
+constexpr int kNotApplicable = 1;  // internal: a hot-path launcher declined, use the generic kernels
 
 int floor_pow2(int v) {
   int p = 1;
@@ -238,7 +239,7 @@ int launch_fwd_fast_t(KP g, const void* x, void* out, float* saved, hipStream_t 
   size_t red = (size_t)(g.G + 1) * (NF + 1) * g.P * 4;
   if (POOL) red += (size_t)Win<R>::N * g.P * 4;  // pooled-map staging
   size_t lds = slab > red ? slab : red;
-  if (lds > (size_t)kLdsMax) return fail(NFP_E_UNSUPPORTED, "fwd_fast: LDS %zu", lds);
+  if (lds > (size_t)kLdsMax) return kNotApplicable;  // tables + slab do not fit: the generic kernels serve it
   if (int rc = set_lds(fwd_fast<R, M, BF, NHWC, POOL, MAXT>, lds)) return rc;
   hipLaunchKernelGGL((fwd_fast<R, M, BF, NHWC, POOL, MAXT>), dim3(g.B), dim3(T), lds, st, g, x, out, saved, gap, nfpm);
   g_launches++;
@@ -283,7 +284,7 @@ int launch_bwd_fast_t(KP g, const void* x, const void* go, const void* out, cons
   size_t slab = (size_t)(g.Cc / 4) * ((g.P + 3) & ~3) * 16;
   size_t xs = slab > tables ? slab : tables;
   size_t lds = ((wt + 15) & ~(size_t)15) + xs;
-  if (lds > (size_t)kLdsMax) return fail(NFP_E_UNSUPPORTED, "bwd_fast: LDS %zu", lds);
+  if (lds > (size_t)kLdsMax) return kNotApplicable;  // tables + slab do not fit: the generic kernels serve it
   if (int rc = set_lds(bwd_fast<R, M, BF, NHWC, POOL>, lds)) return rc;
   hipLaunchKernelGGL((bwd_fast<R, M, BF, NHWC, POOL>), dim3(g.B, S), dim3(T), lds, st, g, x, go, out, saved, gx, ggap,
                      gnfpm);
@@ -342,11 +343,14 @@ int nfp_forward(const nfp_desc* d, const void* x, void* out, float* saved, void*
   if (g.B == 0) return NFP_OK;
   hipStream_t st = (hipStream_t)hip_stream;
   if (fast_ok(g, x, x)) {
+    int rc;
     if (g.measure == NFP_COSINE)
-      return g.R == 1 ? launch_fwd_fast<1, NFP_COSINE>(g, x, out, saved, st)
-                      : launch_fwd_fast<2, NFP_COSINE>(g, x, out, saved, st);
-    return g.R == 1 ? launch_fwd_fast<1, NFP_NORM>(g, x, out, saved, st)
+      rc = g.R == 1 ? launch_fwd_fast<1, NFP_COSINE>(g, x, out, saved, st)
+                    : launch_fwd_fast<2, NFP_COSINE>(g, x, out, saved, st);
+    else
+      rc = g.R == 1 ? launch_fwd_fast<1, NFP_NORM>(g, x, out, saved, st)
                     : launch_fwd_fast<2, NFP_NORM>(g, x, out, saved, st);
+    if (rc != kNotApplicable) return rc;
   }
   switch (g.measure) {
     case NFP_COSINE: return launch_fwd_generic<NFP_COSINE>(g, x, out, saved, st);
@@ -390,11 +394,14 @@ int nfp_backward(const nfp_desc* d, const void* x, const void* grad_out, const v
   if (g.B == 0) return NFP_OK;
   hipStream_t st = (hipStream_t)hip_stream;
   if (fast_ok(g, x, grad_x)) {
+    int rc;
     if (g.measure == NFP_COSINE)
-      return g.R == 1 ? launch_bwd_fast<1, NFP_COSINE>(g, x, grad_out, out, saved, grad_x, st)
-                      : launch_bwd_fast<2, NFP_COSINE>(g, x, grad_out, out, saved, grad_x, st);
-    return g.R == 1 ? launch_bwd_fast<1, NFP_NORM>(g, x, grad_out, out, saved, grad_x, st)
+      rc = g.R == 1 ? launch_bwd_fast<1, NFP_COSINE>(g, x, grad_out, out, saved, grad_x, st)
+                    : launch_bwd_fast<2, NFP_COSINE>(g, x, grad_out, out, saved, grad_x, st);
+    else
+      rc = g.R == 1 ? launch_bwd_fast<1, NFP_NORM>(g, x, grad_out, out, saved, grad_x, st)
                     : launch_bwd_fast<2, NFP_NORM>(g, x, grad_out, out, saved, grad_x, st);
+    if (rc != kNotApplicable) return rc;
   }
   switch (g.measure) {
     case NFP_COSINE: return launch_bwd_generic<NFP_COSINE>(g, x, grad_out, out, saved, grad_x, st);
@@ -433,8 +440,11 @@ int nfp_backward(const nfp_desc* d, const void* x, const void* grad_out, const v
 int nfp_pool_supported(const nfp_desc* d) {
   KP g;
   if (make_kp(d, &g)) return 0;
-  // hot-path geometry, NCHW float32 (x pointer alignment does not matter for NCHW)
-  return g.dtype == NFP_F32 && g.contig && fast_ok(g, nullptr, nullptr) ? 1 : 0;
+  // hot-path geometry, NCHW float32 (x pointer alignment does not matter for NCHW), tables must fit LDS
+  if (!(g.dtype == NFP_F32 && g.contig && fast_ok(g, nullptr, nullptr))) return 0;
+  const int K2 = g.k * g.k;
+  const size_t bwd_tables = (size_t)g.P * K2 * 4 + (size_t)(4 * g.P * g.N + g.P * K2 + (g.R >= 2 ? 2 * g.P * K2 + g.P : 0)) * 4;
+  return bwd_tables + 64 <= (size_t)kLdsMax ? 1 : 0;  // the x slab shares the tables' region (they are dead by then)
 }
 
 int nfp_pool_forward(const nfp_desc* d, const void* x, float* gap, float* nfpm, void* out_map, float* saved,

@@ -405,3 +405,53 @@ def test_c_abi_direct_calls_match_reference_golden(name, dev):
         assert rel_err(gx.cpu().numpy(), g["gx"]) <= TOL
     else:
         assert rel_err(gx.cpu().numpy().reshape(-1)[K.gx_sample_index(gx.numel())], g["gx_sample"]) <= TOL
+
+
+# ---- shape sweep: hot-path staging / chunking corner cases against the float64 torch formulation ----
+
+def _sweep_cases():
+    import itertools, random
+    rnd = random.Random(1234)
+    cases = []
+    # every P % 4, tiny and large channel counts, chunked slabs (C*P*4 beyond one LDS slab), B above/below CU count
+    for (H, W) in [(2, 2), (2, 3), (3, 3), (3, 5), (5, 5), (7, 7), (6, 9), (14, 14), (11, 13), (16, 16), (22, 23), (5, 100)]:
+        for R in (1, 2):
+            if R >= H or R >= W:
+                continue
+            C = rnd.choice([4, 8, 36, 100, 192, 512])
+            B = rnd.choice([1, 3, 17, 70])
+            meas = rnd.choice(["cosine", "norm"])
+            mode = rnd.choice(["reflect", "zeros", "replicate"])
+            cases.append((B, C, H, W, R, meas, mode))
+    cases += [(2, 2048, 7, 7, 1, "cosine", "reflect"),      # ResNet50_NFPPooling width (texture_pooling.py:547-561)
+              (300, 64, 7, 7, 1, "cosine", "reflect"),       # more images than CUs: two workgroups per CU
+              (5, 1000, 3, 3, 1, "norm", "zeros"),
+              (1, 4, 4, 1, 1, "cosine", "replicate") if False else (1, 4, 4, 4, 1, "cosine", "replicate"),
+              (3, 516, 9, 9, 2, "cosine", "reflect")]
+    return cases
+
+
+@pytest.mark.parametrize("B,C,H,W,R,meas,mode", _sweep_cases())
+def test_shape_sweep_against_float64_formulation(B, C, H, W, R, meas, mode, dev):
+    from neighbour_feature_pooling_amd import NFPPooling
+    from neighbour_feature_pooling_amd._host import nfp_host
+    from neighbour_feature_pooling_amd.synth import feature_map
+    ctor = dict(R=R, measure=meas, padding=R, padding_mode=mode)
+    if meas == "norm":
+        ctor["p"] = 2
+    m = NFPPooling(C, **ctor)
+    x = torch.from_numpy(feature_map((B, C, H, W), 7 * H + W + C)).to(dev).requires_grad_(True)
+    out = m(x)
+    go = torch.from_numpy(feature_map(tuple(out.shape), 3 * H + W)).to(dev)
+    gx, = torch.autograd.grad(out, x, go)
+    x64 = x.detach().double().requires_grad_(True)
+    ref = nfp_host(x64, m.config)
+    gref, = torch.autograd.grad(ref, x64, go.double())
+    assert rel_err(out.detach().cpu().numpy(), ref.detach().cpu().numpy()) <= TOL
+    assert rel_err(gx.cpu().numpy(), gref.cpu().numpy()) <= TOL
+    # channels-last view of the same tensor goes through the NHWC staging path
+    xl = x.detach().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    outl = m(xl)
+    gxl, = torch.autograd.grad(outl, xl, go)
+    assert rel_err(outl.detach().cpu().numpy(), ref.detach().cpu().numpy()) <= TOL
+    assert rel_err(gxl.cpu().numpy(), gref.cpu().numpy()) <= TOL
