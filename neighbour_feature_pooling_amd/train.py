@@ -65,17 +65,22 @@ def main():
     ap.add_argument("--nfp-radius", type=int, default=1)
     ap.add_argument("--nfp-measure", default="cosine")
     ap.add_argument("--cpu", action="store_true", help="gloo on CPU (plumbing test)")
+    ap.add_argument("--backend", default=None, help="override the process-group backend (gloo lets several "
+                    "ranks share one GPU for rehearsal; RCCL refuses that)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = a.backend or ("gloo" if a.cpu else "nccl")
+    if not a.cpu and backend == "gloo":
+        local %= torch.cuda.device_count()
     dev = torch.device("cpu") if a.cpu else torch.device("cuda", local)
     if not a.cpu:
         torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo" if a.cpu else "nccl")
+        dist.init_process_group(backend)
     dtype = torch.float32 if a.dtype == "f32" else torch.bfloat16
     torch.manual_seed(0)  # identical initial weights on every rank (DDP also broadcasts rank 0's)
     C = {"resnet18": 512, "vit_tiny_patch16_224": 192, "mobilenetv3_large_100": 960}[a.model]
