@@ -9,6 +9,8 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
+#include <unordered_map>
 
 #include <cstdlib>
 
@@ -95,11 +97,21 @@ int stats_of(int measure) {
   }
 }
 
+// Kernels that want more than 64 KiB of dynamic LDS must be told so once (per kernel and size class);
+// remembered here so that steady-state launches make no extra runtime call.
 template <typename K>
 int set_lds(K kernel, size_t bytes) {
   if (bytes <= 64 * 1024) return NFP_OK;
-  return hip_ok(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes),
-                "hipFuncSetAttribute(max dynamic LDS)");
+  static std::mutex mu;
+  static std::unordered_map<const void*, size_t> granted;
+  std::lock_guard<std::mutex> lock(mu);
+  size_t& have = granted[(const void*)kernel];
+  if (have >= bytes) return NFP_OK;
+  if (int rc = hip_ok(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMax),
+                      "hipFuncSetAttribute(max dynamic LDS)"))
+    return rc;
+  have = kLdsMax;
+  return NFP_OK;
 }
 
 // ---- generic launches -----------------------------------------------------------------------
