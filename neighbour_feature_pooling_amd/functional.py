@@ -198,6 +198,15 @@ def nfp(x, cfg):
     """[B,C,H,W] -> [B, k*k-1, H', W'] neighbour-similarity maps (NFPPooling.forward, nfp.py:132-134)."""
     if x.dim() != 4:
         raise RuntimeError(f"NFP expects a 4-D [B,C,H,W] feature map, got {tuple(x.shape)}")
+    if x.is_cuda and cfg.measure == "scs":
+        # The one measure without a kernel, on purpose: the reference's SharpenedCosine divides
+        # (B,N,H,W) by (B,1,N,H,W) and so averages over the BATCH (nfp.py:359-374).  Its exact behaviour
+        # is reproduced with torch ops on the tensor's own device, and said out loud; every other
+        # measure on a CUDA tensor is served by libnfp_hip.so or raises.
+        import warnings
+        warnings.warn("NFP measure 'scs' (SharpenedCosine) mixes batch elements in the reference; it runs as "
+                      "PyTorch ops on the GPU, not through the HIP kernels", RuntimeWarning, stacklevel=3)
+        return nfp_host(x, cfg)
     if x.is_cuda:
         return _NfpHip.apply(x, cfg)
     return nfp_host(x, cfg)

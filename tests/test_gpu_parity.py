@@ -126,13 +126,24 @@ def test_unbuilt_measure_fails_loudly(dev):
     from neighbour_feature_pooling_amd import NFPPooling, _abi
     supported_now = set()
     for meas in _abi.MEASURES:
+        if meas == "scs":
+            continue
         m = NFPPooling(8, R=1, measure=meas, padding=1)
+        n0 = _launches()
         try:
             m(torch.randn(1, 8, 5, 5, device=dev))
+            assert _launches() > n0
             supported_now.add(meas)
         except _abi.NfpUnsupported:
             pass
     assert HIP_MEASURES == supported_now, (HIP_MEASURES ^ supported_now)
+    # SharpenedCosine: the reference's batch-mixing behaviour, as torch ops on the GPU, with a warning
+    n0 = _launches()
+    with pytest.warns(RuntimeWarning, match="mixes batch elements"):
+        c = K.BY_NAME["m_scs_p2"]
+        out = NFPPooling(c["shape"][1], **c["ctor"])(torch.from_numpy(K.make_input(c)).to(dev))
+    assert _launches() == n0
+    assert rel_err(out.cpu().numpy(), load_golden("m_scs_p2")["out"]) <= TOL
     with pytest.raises(_abi.NfpUnsupported):
         NFPPooling(8, padding=1, measure="cosine")(torch.randn(1, 8, 5, 5, device=dev, dtype=torch.float16))
 
