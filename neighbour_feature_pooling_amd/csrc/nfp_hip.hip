@@ -66,6 +66,10 @@ int make_kp(const nfp_desc* d, KP* g) {
     return fail(NFP_E_INVALID, "reflect padding %d must be smaller than the input %dx%d", d->pad, d->H, d->W);
   if (d->pad_mode == NFP_PAD_CIRCULAR && (d->pad > d->H || d->pad > d->W))
     return fail(NFP_E_INVALID, "circular padding %d must not exceed the input %dx%d", d->pad, d->H, d->W);
+  // LA.norm(ord=p) also takes inf, 0 and negative orders (max / count / min semantics): no kernel for those.
+  if (d->measure == NFP_NORM && !(d->p > 0.f && d->p <= 3.0e38f))
+    return fail(NFP_E_UNSUPPORTED, "norm order p=%g has no HIP kernel (finite p > 0 only)", (double)d->p);
+  if (!(d->eps >= 0.f)) return fail(NFP_E_INVALID, "bad eps %g", (double)d->eps);
   memset(g, 0, sizeof(*g));
   g->B = d->B; g->C = d->C; g->H = d->H; g->W = d->W; g->P = d->H * d->W;
   g->R = d->R; g->k = k; g->N = k * k - 1; g->pad = d->pad; g->stride = d->stride; g->dil = d->dilation;

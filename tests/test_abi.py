@@ -85,6 +85,11 @@ def test_invalid_descriptors_are_refused(lib):
         rc = lib.nfp_output_shape(ctypes.byref(d), ctypes.byref(n), ctypes.byref(n), ctypes.byref(n))
         assert rc == -1
         assert lib.nfp_last_error()
+    for p in (float("inf"), 0.0, -1.0, float("nan")):   # LA.norm orders without a kernel: refused, not mis-computed
+        d = _desc((1, 4, 5, 5), measure="norm")
+        d.p = p
+        assert lib.nfp_output_shape(ctypes.byref(d), ctypes.byref(n), ctypes.byref(n), ctypes.byref(n)) == -2
+        assert b"norm order" in lib.nfp_last_error()
     d = _desc((1, 4, 5, 5))
     d.measure = 99
     assert lib.nfp_forward(ctypes.byref(d), None, None, None, None) == -1

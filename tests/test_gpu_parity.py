@@ -146,6 +146,28 @@ def test_unbuilt_measure_fails_loudly(dev):
     assert rel_err(out.cpu().numpy(), load_golden("m_scs_p2")["out"]) <= TOL
     with pytest.raises(_abi.NfpUnsupported):
         NFPPooling(8, padding=1, measure="cosine")(torch.randn(1, 8, 5, 5, device=dev, dtype=torch.float16))
+    for p in (float("inf"), 0, -2):           # LA.norm orders with other semantics: refused, never mis-computed
+        with pytest.raises(_abi.NfpUnsupported, match="norm order"):
+            NFPPooling(8, padding=1, measure="norm", p=p)(torch.randn(1, 8, 5, 5, device=dev))
+
+
+@pytest.mark.parametrize("p", [0.5, 1, 1.5, 4])
+def test_general_norm_orders(p, dev):
+    """LA.norm(ord=p) for finite p > 0 (nfp.py:145); the reference's default is p=1."""
+    from neighbour_feature_pooling_amd import NFPPooling
+    m = NFPPooling(16, R=1, measure="norm", p=p, padding=1)
+    x = torch.randn(3, 16, 6, 7, dtype=torch.float64).abs().add_(0.1) * torch.sign(torch.randn(3, 16, 6, 7, dtype=torch.float64))
+    x = x.float().double()                     # both sides see the same fp32-representable input
+    go = torch.randn(3, 8, 6, 7, dtype=torch.float64).float().double()
+    xr = x.clone().requires_grad_(True)
+    ref = m(xr)                                # float64 host formulation
+    (gref,) = torch.autograd.grad(ref, xr, go)
+    xd = x.float().to(dev).requires_grad_(True)
+    out = m(xd)
+    (gx,) = torch.autograd.grad(out, xd, go.float().to(dev))
+    assert rel_err(out.detach().cpu().numpy(), ref.detach().numpy()) <= TOL
+    e = rel_err(gx.cpu().numpy(), gref.numpy())
+    assert e <= (5e-5 if p < 1 else TOL), e    # |v|^(p-1) amplifies fp32 rounding of v = a - b for p < 1
 
 
 # ---- properties at the BASELINE.json headline size [64,512,7,7] k=3 cosine -------------------
