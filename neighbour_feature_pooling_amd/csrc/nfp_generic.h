@@ -8,12 +8,13 @@
 //   o; lanes of one output are adjacent, so the channel reduction is a wavefront
 //   shuffle; lane 0 finalises and stores out[b, n, o].
 // Backward (replaces autograd through cosine_similarity / linalg.norm, conv2d
-//   backward and reflection_pad backward):
-//   grid (B, channel blocks).  grad_x of the chunk is accumulated in LDS with
-//   ds_add_f32 (the pad/stride adjoint is just "add at the mapped index"), then
-//   written once, coalesced.  Summation order inside LDS is not fixed, so this
-//   path is reproducible to rounding only; the fast path (nfp_fast.h) is bitwise
-//   deterministic.
+//   backward and reflection_pad backward): the gather-form kernel of nfp_gather.h
+//   serves every map whose index tables fit in LDS.  bwd_generic below is the
+//   fallback for larger maps: grid (B, channel blocks), grad_x of the chunk is
+//   accumulated in LDS with ds_add_f32 (the pad/stride adjoint is just "add at the
+//   mapped index"), then written once, coalesced.  Summation order inside LDS is
+//   not fixed, so this fallback is reproducible to rounding only; nfp_gather.h and
+//   the fast path (nfp_fast.h) are bitwise deterministic.
 #pragma once
 #include "nfp_measures.h"
 

@@ -5,6 +5,7 @@
 // loudly (NFP_E_HIP / NFP_E_UNSUPPORTED) rather than fall back.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <atomic>
 #include <cstdarg>
 #include <cstdio>
@@ -15,6 +16,7 @@
 #include <cstdlib>
 
 #include "nfp_fast.h"
+#include "nfp_gather.h"
 #include "nfp_generic.h"
 
 using namespace nfp;
@@ -144,9 +146,82 @@ int launch_fwd_generic(KP g, const void* x, void* out, float* saved, hipStream_t
   return hip_ok(hipGetLastError(), "launch fwd_generic");
 }
 
+// Gather-form backward (nfp_gather.h): tables + one slab of >= QB channel quads must fit in LDS and the
+// packed 16-bit indices must hold; otherwise the LDS-atomic kernel below serves the call.
+bool force_atomic() {
+  const char* e = getenv("NFP_BWD_ATOMIC");
+  return e && e[0] == '1';
+}
+
+#ifndef NFP_GATHER_WGS
+#define NFP_GATHER_WGS 512
+#endif
+#ifndef NFP_GATHER_QB
+#define NFP_GATHER_QB 4
+#endif
+#ifndef NFP_GATHER_SLAB_KB
+#define NFP_GATHER_SLAB_KB 48
+#endif
+
+template <int M>
+int launch_bwd_gather(const KP& g, const void* x, const void* go, const void* out, const float* saved, void* gx,
+                      hipStream_t st) {
+  constexpr int QB = NFP_GATHER_QB, NC = NCoef<M>::v;
+  const long long ON = (long long)g.O * g.N;
+  // index ranges the packed tables hold (nfp_gather.h)
+  if (force_atomic() || ON > 65535 || g.P > 65534 || g.k > 15 || g.pad > 8 || g.H >= 16383 || g.W >= 16383)
+    return kNotApplicable;
+  auto folds = [&](int n) {  // padded coordinates that can fold onto one coordinate of an axis of size n
+    if (g.pad == 0 || g.mode == NFP_PAD_ZEROS) return 1;
+    if (g.mode == NFP_PAD_REPLICATE) return n == 1 ? 2 * g.pad + 1 : g.pad + 1;
+    return 3;
+  };
+  GatherLds L;
+  L.ON = (int)ON;
+  L.capY = g.k * folds(g.H);
+  L.capX = g.k * folds(g.W);
+  long long w = 0;
+  L.cf = (int)w;  w += (long long)NC * L.ON;
+  L.nbq = (int)w; w += (L.ON + 1) / 2;
+  w = (w + 1) & ~1LL;  // uint2 lists
+  L.yl = (int)w;  w += 2LL * g.H * L.capY;
+  L.xl = (int)w;  w += 2LL * g.W * L.capX;
+  L.yc = (int)w;  w += g.H;
+  L.xc = (int)w;  w += g.W;
+  w = (w + 3) & ~3LL;
+  if (w * 4 > kLdsMax) return kNotApplicable;
+  L.xs = (int)w;
+  const size_t table_bytes = (size_t)w * 4, quad_bytes = (size_t)(g.P + 1) * 16;
+  const size_t slot_bytes = (size_t)(g.H + g.W) * (2 * g.pad + 1) * g.k * 8;  // scratch that precedes the first slab
+  if (table_bytes + QB * quad_bytes > (size_t)kLdsMax || table_bytes + slot_bytes > (size_t)kLdsMax)
+    return kNotApplicable;
+  const int Q = (g.C + 3) / 4;
+  // channel split: enough workgroups to fill the chip at small batch, whole QB blocks per workgroup
+  int S = (NFP_GATHER_WGS + g.B - 1) / g.B;
+  const int maxS = (Q + QB - 1) / QB;
+  if (S > maxS) S = maxS;
+  if (S < 1) S = 1;
+  L.Qwg = (((Q + S - 1) / S) + QB - 1) / QB * QB;
+  S = (Q + L.Qwg - 1) / L.Qwg;
+  // slab: what the workgroup needs, capped by a budget that keeps several workgroups per CU, then by LDS
+  size_t budget = (size_t)NFP_GATHER_SLAB_KB * 1024;
+  if (budget < QB * quad_bytes) budget = QB * quad_bytes;
+  if (budget > (size_t)kLdsMax - table_bytes) budget = (size_t)kLdsMax - table_bytes;
+  int Cq = (int)(budget / quad_bytes) / QB * QB;
+  if (Cq > L.Qwg) Cq = L.Qwg;
+  L.Cq = Cq;
+  const size_t lds = table_bytes + std::max((size_t)Cq * quad_bytes, slot_bytes);
+  if (int rc = set_lds(bwd_gather<M, QB>, lds)) return rc;
+  hipLaunchKernelGGL((bwd_gather<M, QB>), dim3(g.B, S), dim3(512), lds, st, g, L, x, go, out, saved, gx);
+  g_launches++;
+  snprintf(g_variant, sizeof(g_variant), "bwd_gather");
+  return hip_ok(hipGetLastError(), "launch bwd_gather");
+}
+
 template <int M>
 int launch_bwd_generic(KP g, const void* x, const void* go, const void* out, const float* saved, void* gx,
                        hipStream_t st) {
+  if (int rc = launch_bwd_gather<M>(g, x, go, out, saved, gx, st); rc != kNotApplicable) return rc;
   g.Cc = kLdsBudgetBwd / (g.P * 4);
   if (g.Cc < 1) g.Cc = 1;
   if (g.Cc > g.C) g.Cc = g.C;

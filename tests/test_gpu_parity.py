@@ -61,11 +61,13 @@ def _supported(c):
     return c["ctor"]["measure"].lower() in HIP_MEASURES
 
 
-@pytest.fixture(params=["auto", "generic"])
+@pytest.fixture(params=["auto", "generic", "atomic"])
 def variant(request, monkeypatch):
     """'auto' = the dispatcher's choice (hot-path kernels where they apply); 'generic' forces the
-    any-geometry kernels, so both implementations are held to the same bar on every case."""
-    monkeypatch.setenv("NFP_FORCE_GENERIC", "1" if request.param == "generic" else "0")
+    any-geometry kernels (gather-form backward); 'atomic' additionally forces the LDS-atomic backward that
+    serves maps too large for the gather tables — every implementation is held to the same bar on every case."""
+    monkeypatch.setenv("NFP_FORCE_GENERIC", "0" if request.param == "auto" else "1")
+    monkeypatch.setenv("NFP_BWD_ATOMIC", "1" if request.param == "atomic" else "0")
     return request.param
 
 
@@ -315,20 +317,37 @@ def test_nfp_inside_network_matches_torch_formulation(dev):
     net = build("resnet18", num_classes=6, in_chans=3, image=96, device=dev).eval()
     x, y = synthetic_batch(8, 3, 96, 6, dev, torch.float32, 5)
     crit = torch.nn.CrossEntropyLoss(label_smoothing=0.05)
-    crit(net(x), y).backward()
-    g_hip = {k: p.grad.clone() for k, p in net.named_parameters()}
-    net.zero_grad()
-    orig = functional.nfp_pool
-    try:  # second pass: both pooled reductions from torch ops on the GPU instead of the HIP kernels
-        import neighbour_feature_pooling_amd.pooling as pooling
-        pooling.nfp_pool = lambda t, cfg: (t.mean((2, 3)), nfp_host(t, cfg).mean((2, 3)))
+    feat_grads = []
+    hook = net.pool.register_forward_pre_hook(
+        lambda mod, args: args[0].register_hook(lambda g: feat_grads.append(g.clone())) and None)
+    import neighbour_feature_pooling_amd.pooling as pooling
+    orig = pooling.nfp_pool
+    try:
+        n0 = _launches()
         crit(net(x), y).backward()
+        assert _launches() >= n0 + 2
+        g_hip = {k: p.grad.clone() for k, p in net.named_parameters()}
+        net.zero_grad()
+        # second pass: both pooled reductions from torch ops on the GPU instead of the HIP kernels
+        pooling.nfp_pool = lambda t, cfg: (t.mean((2, 3)), nfp_host(t, cfg).mean((2, 3)))
+        n0 = _launches()
+        crit(net(x), y).backward()
+        assert _launches() == n0
     finally:
         pooling.nfp_pool = orig
+        hook.remove()
+    # what the NFP backward hands to the backbone: the same forward features both times, so only the two NFP
+    # implementations (and the head) differ
+    assert len(feat_grads) == 2
+    assert (feat_grads[0] - feat_grads[1]).abs().max().item() <= 1e-4 * feat_grads[1].abs().max().item()
     for k, p in net.named_parameters():
         ref = p.grad
-        # 2e-3: MIOpen's conv weight-gradient kernels are not bitwise reproducible between two passes
-        assert (g_hip[k] - ref).abs().max().item() <= 2e-3 * max(ref.abs().max().item(), 1e-6), k
+        if k.startswith(("pool.", "fc.")):
+            assert (g_hip[k] - ref).abs().max().item() <= 1e-4 * max(ref.abs().max().item(), 1e-6), k
+        else:
+            # through MIOpen's conv backward kernels, whose choice (Winograd / implicit GEMM, atomic split-K)
+            # and rounding are not the same from one pass to the next: a sanity bound only
+            assert (g_hip[k] - ref).norm().item() <= 2e-2 * max(ref.norm().item(), 1e-6), k
 
 
 def test_vit_tiny_nfp_bf16_k5_l2_step(dev):
