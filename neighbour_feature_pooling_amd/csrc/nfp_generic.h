@@ -147,6 +147,20 @@ __global__ void __launch_bounds__(1024) fwd_generic(const KP g, const void* __re
   float sa0 = 0.f, sa1 = 0.f;
 #pragma unroll
   for (int j = 0; j < kGroup; ++j) acc[j] = sb0[j] = sb1[j] = 0.f;
+  // pivots (nfp_measures.h::Pivot): channel 0 of the centre and of each neighbour; 0 for zero-padded taps
+  float pa = 0.f, pb[kGroup];
+#pragma unroll
+  for (int j = 0; j < kGroup; ++j) pb[j] = 0.f;
+  if constexpr (Pivot<M>::v) {
+    auto pix0 = [&](int p) {
+      const int y = p / g.W, xx = p - y * g.W;
+      return ldx(x, (long long)b * g.sB + (long long)y * g.sH + (long long)xx * g.sW, g.dtype);
+    };
+    if (pc >= 0) pa = pix0(pc);
+#pragma unroll
+    for (int j = 0; j < kGroup; ++j)
+      if (q[j] >= 0) pb[j] = pix0(q[j]);
+  }
 
   for (int c0 = 0; c0 < g.C; c0 += g.Cc) {
     const int cc = min(g.Cc, g.C - c0);
@@ -157,10 +171,12 @@ __global__ void __launch_bounds__(1024) fwd_generic(const KP g, const void* __re
       for (int c = gl; c < cc; c += g.G) {
         const float* row = xs + c * g.P;
         float a = pc >= 0 ? row[pc] : 0.f;
+        if constexpr (Pivot<M>::v) a -= pa;
         Meas<M>::stat(a, sa0, sa1);
 #pragma unroll
         for (int j = 0; j < kGroup; ++j) {
           float bv = q[j] >= 0 ? row[q[j]] : 0.f;
+          if constexpr (Pivot<M>::v) bv -= pb[j];
           acc[j] += Meas<M>::term(a, bv, g);
           Meas<M>::stat(bv, sb0[j], sb1[j]);
         }
@@ -192,13 +208,13 @@ __global__ void __launch_bounds__(1024) fwd_generic(const KP g, const void* __re
       // all with a value summed in the same order (benign duplicate stores)
       float* sv = saved + (long long)b * Meas<M>::NSTAT * g.P;
       if (pc >= 0) {
-        sv[pc] = Meas<M>::save0(sa0, sa1, g);
+        sv[pc] = Meas<M>::save0(sa0, sa1, g) + (Pivot<M>::v ? pa : 0.f);
         if (Meas<M>::NSTAT > 1) sv[g.P + pc] = Meas<M>::save1(sa0, sa1, g);
       }
 #pragma unroll
       for (int j = 0; j < kGroup; ++j)
         if (q[j] >= 0) {
-          sv[q[j]] = Meas<M>::save0(sb0[j], sb1[j], g);
+          sv[q[j]] = Meas<M>::save0(sb0[j], sb1[j], g) + (Pivot<M>::v ? pb[j] : 0.f);
           if (Meas<M>::NSTAT > 1) sv[g.P + q[j]] = Meas<M>::save1(sb0[j], sb1[j], g);
         }
     }

@@ -507,3 +507,56 @@ def test_shape_sweep_against_float64_formulation(B, C, H, W, R, meas, mode, dev)
     gxl, = torch.autograd.grad(outl, xl, go)
     assert rel_err(outl.detach().cpu().numpy(), ref.detach().cpu().numpy()) <= TOL
     assert rel_err(gxl.cpu().numpy(), gref.cpu().numpy()) <= TOL
+
+
+def _gather_cases():
+    import random
+    rnd = random.Random(4321)
+    cases = []
+    meas_pool = ["dot", "norm", "emd", "cosine", "gfc", "pearson", "smith", "canberra", "geman", "chisquared2"]
+    for mode in ("reflect", "zeros", "replicate", "circular"):
+        for (H, W, R, pad, stride, dil) in [(7, 7, 1, 1, 1, 1), (6, 9, 1, 3, 1, 1), (9, 8, 2, 1, 2, 1),
+                                            (11, 10, 1, 2, 3, 2), (5, 12, 2, 4, 1, 2), (1, 9, 1, 0, 1, 1),
+                                            (8, 1, 1, 0, 1, 1), (4, 4, 1, 3, 2, 1), (13, 6, 3, 2, 1, 1)]:
+            k = 2 * R + 1
+            if H + 2 * pad < dil * (k - 1) + 1 or W + 2 * pad < dil * (k - 1) + 1:
+                continue
+            if mode == "reflect" and (pad >= H or pad >= W):
+                continue
+            if mode == "circular" and (pad > H or pad > W):
+                continue
+            cases.append((rnd.choice([1, 3, 5]), rnd.choice([3, 5, 8, 18, 67]), H, W, R, pad, stride, dil, mode,
+                          rnd.choice(meas_pool)))
+    return cases
+
+
+@pytest.mark.parametrize("B,C,H,W,R,pad,stride,dil,mode,meas", _gather_cases())
+def test_gather_backward_geometry_sweep(B, C, H, W, R, pad, stride, dil, mode, meas, dev, monkeypatch):
+    """The gather-form backward (nfp_gather.h) inverts pad/stride/dilation analytically: every padding mode,
+    pixels that are the centre of none or of several outputs, 1-pixel-wide maps, channel counts that are not
+    a multiple of 4 — against the float64 formulation, bitwise reproducible, and equal to the atomic fallback."""
+    from neighbour_feature_pooling_amd import NFPPooling, _abi
+    from neighbour_feature_pooling_amd._host import nfp_host
+    monkeypatch.setenv("NFP_FORCE_GENERIC", "1")
+    monkeypatch.setenv("NFP_BWD_ATOMIC", "0")
+    ctor = dict(R=R, measure=meas, padding=pad, stride=stride, dilation=dil, padding_mode=mode)
+    if meas == "norm":
+        ctor["p"] = 1
+    m = NFPPooling(C, **ctor)
+    g = torch.Generator().manual_seed(H * 131 + W * 17 + C)
+    x = (torch.rand(B, C, H, W, generator=g) + 0.25).to(dev).requires_grad_(True)   # positive: valid for every measure
+    out = m(x)
+    go = torch.randn(out.shape, generator=g).to(dev)
+    gx, = torch.autograd.grad(out, x, go, retain_graph=True)
+    assert _abi.load().nfp_last_variant().decode() == "bwd_gather"
+    gx2, = torch.autograd.grad(out, x, go, retain_graph=True)
+    assert torch.equal(gx, gx2)
+    x64 = x.detach().double().requires_grad_(True)
+    ref = nfp_host(x64, m.config)
+    gref, = torch.autograd.grad(ref, x64, go.double())
+    assert rel_err(out.detach().cpu().numpy(), ref.detach().cpu().numpy()) <= TOL
+    assert rel_err(gx.cpu().numpy(), gref.cpu().numpy()) <= 2 * TOL
+    monkeypatch.setenv("NFP_BWD_ATOMIC", "1")
+    gx3, = torch.autograd.grad(out, x, go)
+    assert _abi.load().nfp_last_variant().decode() == "bwd_generic"
+    assert rel_err(gx3.cpu().numpy(), gref.cpu().numpy()) <= 2 * TOL
