@@ -104,4 +104,11 @@ __device__ unsigned long long* nfp_stamp_buf = nullptr;
 
 __device__ __forceinline__ float sgnf(float v) { return (float)((v > 0.f) - (v < 0.f)); }
 
+// Per-channel arithmetic of the measures (term / grad, evaluated C*N times per output pixel): hardware
+// reciprocal and square root (1 ulp) instead of the ~10-instruction IEEE sequences.  x/0, 0/0 and inf/inf
+// give the same inf / NaN as a true division; every denominator they see is >= eps by construction.
+__device__ __forceinline__ float frcp(float b) { return __builtin_amdgcn_rcpf(b); }
+__device__ __forceinline__ float fdiv(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+__device__ __forceinline__ float fsqrt(float v) { return __builtin_amdgcn_sqrtf(v); }
+
 }  // namespace nfp

@@ -151,7 +151,7 @@ struct Meas<NFP_GEMAN> {
   static constexpr int NSTAT = 0;
   __device__ static __forceinline__ float term(float a, float b, const KP& g) {
     float q = (a - b) * (a - b);
-    return q / (q + g.eps);
+    return fdiv(q, q + g.eps);
   }
   __device__ static __forceinline__ void stat(float, float&, float&) {}
   __device__ static __forceinline__ float fin(float acc, float, float, float, float, const KP& g) {
@@ -163,8 +163,8 @@ struct Meas<NFP_GEMAN> {
     return c;
   }
   __device__ static __forceinline__ void grad(float a, float b, const Coef& c, const KP& g, float& da, float& db) {
-    float v = a - b, q = v * v + g.eps;
-    da = c.k0 * 2.f * v * g.eps / (q * q);
+    float v = a - b, iq = frcp(v * v + g.eps);
+    da = c.k0 * 2.f * v * g.eps * iq * iq;
     db = -da;
   }
 };
@@ -193,7 +193,7 @@ template <>
 struct Meas<NFP_CANBERRA> {
   static constexpr int NSTAT = 0;
   __device__ static __forceinline__ float term(float a, float b, const KP& g) {
-    return fabsf(a - b) / (fabsf(a) + fabsf(b) + g.eps);
+    return fdiv(fabsf(a - b), fabsf(a) + fabsf(b) + g.eps);
   }
   __device__ static __forceinline__ void stat(float, float&, float&) {}
   __device__ static __forceinline__ float fin(float acc, float, float, float, float, const KP& g) {
@@ -204,9 +204,9 @@ struct Meas<NFP_CANBERRA> {
     return c;
   }
   __device__ static __forceinline__ void grad(float a, float b, const Coef& c, const KP& g, float& da, float& db) {
-    float u = fabsf(a - b), w = fabsf(a) + fabsf(b) + g.eps, s = sgnf(a - b);
-    da = c.k0 * (s / w - u * sgnf(a) / (w * w));
-    db = c.k0 * (-s / w - u * sgnf(b) / (w * w));
+    float u = fabsf(a - b), iw = frcp(fabsf(a) + fabsf(b) + g.eps), s = sgnf(a - b);
+    da = c.k0 * iw * (s - u * iw * sgnf(a));
+    db = c.k0 * iw * (-s - u * iw * sgnf(b));
   }
 };
 
@@ -215,7 +215,7 @@ template <int WHICH>
 struct MeasChord {
   static constexpr int NSTAT = 0;
   __device__ static __forceinline__ float term(float a, float b, const KP& g) {
-    float r = sqrtf(fabsf(a) + g.eps) - sqrtf(fabsf(b) + g.eps);
+    float r = fsqrt(fabsf(a) + g.eps) - fsqrt(fabsf(b) + g.eps);
     return r * r;
   }
   __device__ static __forceinline__ void stat(float, float&, float&) {}
@@ -229,9 +229,9 @@ struct MeasChord {
     return c;
   }
   __device__ static __forceinline__ void grad(float a, float b, const Coef& c, const KP& g, float& da, float& db) {
-    float ra = sqrtf(fabsf(a) + g.eps), rb = sqrtf(fabsf(b) + g.eps);
-    da = c.k0 * ((ra - rb) / ra) * sgnf(a);
-    db = c.k0 * (-(ra - rb) / rb) * sgnf(b);
+    float ra = fsqrt(fabsf(a) + g.eps), rb = fsqrt(fabsf(b) + g.eps);
+    da = c.k0 * fdiv(ra - rb, ra) * sgnf(a);
+    db = c.k0 * fdiv(rb - ra, rb) * sgnf(b);
   }
 };
 template <>
@@ -248,7 +248,7 @@ struct MeasChi {
   }
   __device__ static __forceinline__ float term(float a, float b, const KP& g) {
     float v = a - b;
-    return v * v / wden(a, b, g);
+    return fdiv(v * v, wden(a, b, g));
   }
   __device__ static __forceinline__ void stat(float, float&, float&) {}
   __device__ static __forceinline__ float fin(float acc, float, float, float, float, const KP& g) {
@@ -259,9 +259,9 @@ struct MeasChi {
     return c;
   }
   __device__ static __forceinline__ void grad(float a, float b, const Coef& c, const KP& g, float& da, float& db) {
-    float v = a - b, w = wden(a, b, g);
-    da = c.k0 * (2.f * v / w - v * v * sgnf(a) / (w * w));
-    db = c.k0 * (-2.f * v / w - (WHICH == NFP_CHISQUARED1 ? v * v * sgnf(b) / (w * w) : 0.f));
+    float v = a - b, iw = frcp(wden(a, b, g)), t = v * iw;
+    da = c.k0 * (2.f * t - t * t * sgnf(a));
+    db = c.k0 * (-2.f * t - (WHICH == NFP_CHISQUARED1 ? t * t * sgnf(b) : 0.f));
   }
 };
 template <>
@@ -338,8 +338,9 @@ template <>
 struct Meas<NFP_JEFFREY> {
   static constexpr int NSTAT = 0;
   __device__ static __forceinline__ float term(float a, float b, const KP& g) {
+    // ca*log(ca/cb) + cb*log(cb/ca) = (ca - cb)*log(ca/cb): one logarithm, one reciprocal
     float ca = fabsf(a) + g.eps, cb = fabsf(b) + g.eps;
-    return ca * logf(ca / cb) + cb * logf(cb / ca);
+    return (ca - cb) * logf(fdiv(ca, cb));
   }
   __device__ static __forceinline__ void stat(float, float&, float&) {}
   __device__ static __forceinline__ float fin(float acc, float, float, float, float, const KP& g) {
@@ -350,9 +351,9 @@ struct Meas<NFP_JEFFREY> {
     return c;
   }
   __device__ static __forceinline__ void grad(float a, float b, const Coef& c, const KP& g, float& da, float& db) {
-    float ca = fabsf(a) + g.eps, cb = fabsf(b) + g.eps, l = logf(ca / cb);
-    da = c.k0 * (l + 1.f - cb / ca) * sgnf(a);
-    db = c.k0 * (-l + 1.f - ca / cb) * sgnf(b);
+    float ca = fabsf(a) + g.eps, cb = fabsf(b) + g.eps, r = fdiv(ca, cb), l = logf(r);
+    da = c.k0 * (l + 1.f - fdiv(cb, ca)) * sgnf(a);
+    db = c.k0 * (-l + 1.f - r) * sgnf(b);
   }
 };
 
