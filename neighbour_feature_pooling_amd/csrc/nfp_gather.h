@@ -65,6 +65,85 @@ __device__ __forceinline__ uint2 axis_reader(const KP& g, int i, int n, int no, 
   return e;
 }
 
+
+// x[b, 4*qc0 : 4*(qc0+cqn), :, :] -> LDS float4[cq][PS] (PS = P + 1; pixel P of every quad is the zero a
+// zero-padded tap reads); any strides, f32 or bf16; channels past C are 0.  With a pivot table the slab
+// holds x - piv[pixel] (nfp_measures.h::Pivot), so padding channels and the zero pixel stay exact zeros.
+// The four loads of a quad are unconditional (addresses clamped into the tensor, surplus lanes zeroed
+// afterwards): a select or branch around a load makes hipcc wait for each one before issuing the next.
+template <bool BF>
+__device__ __forceinline__ float ld_elem(const void* x, long long i) {
+  if (BF) return bf16_to_f32(((const uint16_t*)x)[i]);
+  return ((const float*)x)[i];
+}
+template <bool BF>
+__device__ __forceinline__ float4 load_quad(const void* x, const KP& g, long long base, int left) {
+  float4 v;
+  v.x = ld_elem<BF>(x, base);
+  v.y = ld_elem<BF>(x, base + min(1, left) * g.sC);
+  v.z = ld_elem<BF>(x, base + min(2, left) * g.sC);
+  v.w = ld_elem<BF>(x, base + min(3, left) * g.sC);
+  return v;
+}
+__device__ __forceinline__ float4 finish_quad(float4 v, int left, float pv) {
+  v.x -= pv;
+  v.y = left >= 1 ? v.y - pv : 0.f;
+  v.z = left >= 2 ? v.z - pv : 0.f;
+  v.w = left >= 3 ? v.w - pv : 0.f;
+  return v;
+}
+template <bool BF>
+__device__ __forceinline__ void stage_quads_t(float4* xs, const void* x, const KP& g, int b, int qc0, int cqn,
+                                              const float* piv) {
+  const int t = threadIdx.x, T = blockDim.x, PS = g.P + 1;
+  // 2-D thread grid, fast axis = what is contiguous in memory: pixels (NCHW) or channel quads (channels-last);
+  // one integer division per thread per call, two quads in flight per thread and iteration.
+  const bool nhwc = g.sC == 1;
+  const bool dense = g.sH == (long long)g.W * g.sW;  // pixel p sits at p * sW: no row / column split needed
+  const int nf = nhwc ? cqn : g.P, ns = nhwc ? g.P : cqn;
+  const int TF = min(nf, T), TS = T / TF;
+  const int tf = t % TF, ts = t / TF;
+  const long long img = (long long)b * g.sB;
+  constexpr int U = 8;  // quads in flight per thread: staging is latency-bound, not issue-bound
+  if (ts < TS) {
+    for (int s0 = ts; s0 < ns; s0 += U * TS) {
+      for (int f = tf; f < nf; f += TF) {
+        float4 v[U];
+        int cqs[U], ps[U], lefts[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int su = min(s0 + u * TS, ns - 1);
+          cqs[u] = nhwc ? f : su;
+          ps[u] = nhwc ? su : f;
+          long long off;
+          if (dense) {
+            off = (long long)ps[u] * g.sW;
+          } else {
+            const int y = ps[u] / g.W;
+            off = (long long)y * g.sH + (long long)(ps[u] - y * g.W) * g.sW;
+          }
+          const int c = 4 * (qc0 + cqs[u]);
+          lefts[u] = g.C - 1 - c;
+          v[u] = load_quad<BF>(x, g, img + (long long)c * g.sC + off, lefts[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const float4 w = finish_quad(v[u], lefts[u], piv ? piv[ps[u]] : 0.f);
+          if (s0 + u * TS < ns) xs[cqs[u] * PS + ps[u]] = w;
+        }
+      }
+    }
+  }
+  for (int cq = t; cq < cqn; cq += T) xs[cq * PS + g.P] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+__device__ __forceinline__ void stage_quads(float4* xs, const void* x, const KP& g, int b, int qc0, int cqn,
+                                            const float* piv = nullptr) {
+  if (g.dtype == NFP_F32)
+    stage_quads_t<false>(xs, x, g, b, qc0, cqn, piv);
+  else
+    stage_quads_t<true>(xs, x, g, b, qc0, cqn, piv);
+}
+
 template <int M>
 __device__ __forceinline__ Coef load_coef(const float* cf, int ON, int j) {
   constexpr int NC = NCoef<M>::v;
@@ -154,33 +233,7 @@ __global__ void __launch_bounds__(512) bwd_gather(const KP g, const GatherLds L,
     const int cqn = min(L.Cq, q_end - qc0);
     __syncthreads();  // tables complete, slots consumed / previous slab consumed
     if (qc0 == q_begin) NFP_STAMP(4);
-    // stage x[b, 4*qc0 : 4*(qc0+cqn), :, :] as float4[cq][p]; channels past C read as 0
-    if (g.sC == 1) {  // channels-last: channel quad fastest -> 16 contiguous bytes per lane
-      for (int i = t; i < cqn * g.P; i += T) {
-        const int p = i / cqn, cq = i - p * cqn;
-        const int y = p / g.W, xx = p - y * g.W, c = 4 * (qc0 + cq);
-        const long long base = (long long)b * g.sB + (long long)y * g.sH + (long long)xx * g.sW + c;
-        float4 v;
-        v.x = ldx(x, base, g.dtype);
-        v.y = c + 1 < g.C ? ldx(x, base + 1, g.dtype) : 0.f;
-        v.z = c + 2 < g.C ? ldx(x, base + 2, g.dtype) : 0.f;
-        v.w = c + 3 < g.C ? ldx(x, base + 3, g.dtype) : 0.f;
-        xs[cq * PS + p] = v;
-      }
-    } else {
-      for (int i = t; i < cqn * g.P; i += T) {
-        const int cq = i / g.P, p = i - cq * g.P;
-        const int y = p / g.W, xx = p - y * g.W, c = 4 * (qc0 + cq);
-        const long long base = (long long)b * g.sB + (long long)c * g.sC + (long long)y * g.sH + (long long)xx * g.sW;
-        float4 v;
-        v.x = ldx(x, base, g.dtype);
-        v.y = c + 1 < g.C ? ldx(x, base + g.sC, g.dtype) : 0.f;
-        v.z = c + 2 < g.C ? ldx(x, base + 2 * g.sC, g.dtype) : 0.f;
-        v.w = c + 3 < g.C ? ldx(x, base + 3 * g.sC, g.dtype) : 0.f;
-        xs[cq * PS + p] = v;
-      }
-    }
-    for (int cq = t; cq < cqn; cq += T) xs[cq * PS + g.P] = zero4;  // what a zero-padded tap reads
+    stage_quads(xs, x, g, b, qc0, cqn);
     __syncthreads();
     if (qc0 == q_begin) NFP_STAMP(5);
     const int nqb = (cqn + QB - 1) / QB;
@@ -256,6 +309,162 @@ __global__ void __launch_bounds__(512) bwd_gather(const KP g, const GatherLds L,
     }
   }
   NFP_STAMP(6);
+}
+
+// ---- forward --------------------------------------------------------------------------------------------
+// Replaces nfp.py:132-159 (pad -> two frozen depthwise convs -> view -> measure over C) for every measure
+// and geometry.  One workgroup = one image x one tile of outputs.  x is staged once per channel chunk into
+// the float4[quad][pixel] slab; thread (output o, channel group) keeps the NN pair sums of o in registers
+// and walks its channel quads with one ds_read_b128 per (quad, neighbour) = four channel terms; the
+// channel groups are then combined through LDS in a fixed order (bitwise deterministic).  What a measure
+// needs per PIXEL (norms, means: Meas::stat) is summed once per pixel, not once per pair.
+struct PairsLds {
+  int xs;    // float4 slab (word offset, multiple of 4)
+  int st;    // float [2][P + 1]  per-pixel stat sums (entry P = the zero pixel = 0)
+  int piv;   // float [P + 1]     per-pixel pivot (nfp_measures.h::Pivot), 0 where unused
+  int tap;   // u16   [N + 1][Ot] input pixel each tap of each output of the tile reads (row N = centre; P = zero)
+  int red;   // float scratch for the cross-group sums
+  int Cq;    // channel quads per slab
+  int Ot;    // outputs per workgroup tile
+  int G;     // channel groups in the pair loop (G * Ot <= blockDim)
+  int Gs;    // channel groups in the per-pixel stat loop
+};
+
+template <int M, int NN>
+__global__ void __launch_bounds__(512) fwd_pairs(const KP g, const PairsLds L, const void* __restrict__ x,
+                                                 void* __restrict__ out, float* __restrict__ saved) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int NS = Meas<M>::NSTAT;
+  float4* xs = (float4*)(lds + L.xs);
+  float* st = lds + L.st;
+  float* piv = lds + L.piv;
+  unsigned short* tap = (unsigned short*)(lds + L.tap);
+  float* red = lds + L.red;
+  const int b = blockIdx.x, t = threadIdx.x, T = blockDim.x;
+  const int PS = g.P + 1, Q = (g.C + 3) >> 2;
+  const int o0 = blockIdx.y * L.Ot, on = min(L.Ot, g.O - o0);
+  const int ol = t % L.Ot, cg = t / L.Ot;
+  const bool active = cg < L.G && ol < on;
+  const int nchunk = (Q + L.Cq - 1) / L.Cq;
+  NFP_STAMP_INIT();
+  NFP_STAMP(0);
+
+  for (int i = t; i < 2 * PS; i += T) st[i] = 0.f;
+  for (int p = t; p < PS; p += T) {
+    float v = 0.f;
+    if (Pivot<M>::v && p < g.P) {
+      const int y = p / g.W, xx = p - y * g.W;
+      v = ldx(x, (long long)b * g.sB + (long long)y * g.sH + (long long)xx * g.sW, g.dtype);
+    }
+    piv[p] = v;
+  }
+  for (int i = t; i < L.Ot * g.k; i += T) {  // tap table of this tile: thread (output, kernel row) walks a row of taps
+    const int ky = i / L.Ot, l = i - ky * L.Ot;
+    const int oy = (o0 + l) / g.Wo, ox = (o0 + l) - oy * g.Wo, mid = (g.k * g.k) >> 1;
+    const int yy = map_index(oy * g.stride + ky * g.dil - g.pad, g.H, g.mode);
+    for (int kx = 0, tp = ky * g.k; kx < g.k; ++kx, ++tp) {
+      const int xx = map_index(ox * g.stride + kx * g.dil - g.pad, g.W, g.mode);
+      const int px = (l < on && yy >= 0 && xx >= 0) ? yy * g.W + xx : g.P;
+      tap[(tp == mid ? g.N : (tp < mid ? tp : tp - 1)) * L.Ot + l] = (unsigned short)px;
+    }
+  }
+  __syncthreads();
+  const int pcz = tap[g.N * L.Ot + ol];
+
+  for (int n0 = 0; n0 < g.N; n0 += NN) {
+    int q[NN];
+    float acc[NN];
+#pragma unroll
+    for (int j = 0; j < NN; ++j) {
+      acc[j] = 0.f;
+      q[j] = n0 + j < g.N ? (int)tap[(n0 + j) * L.Ot + ol] : g.P;
+    }
+    for (int ch = 0; ch < nchunk; ++ch) {
+      const int qc0 = ch * L.Cq, cqn = min(L.Cq, Q - qc0);
+      if (n0 == 0 || nchunk > 1) {
+        __syncthreads();  // previous slab consumed
+        if (ch == 0 && n0 == 0) NFP_STAMP(1);
+        stage_quads(xs, x, g, b, qc0, cqn, Pivot<M>::v ? piv : nullptr);
+        __syncthreads();
+        if (ch == 0 && n0 == 0) NFP_STAMP(2);
+        if (NS > 0 && n0 == 0) {
+          // per-pixel stat sums of this chunk: thread (pixel, group) -> scratch -> st
+          for (int i = t; i < L.Gs * g.P; i += T) {
+            const int gs = i / g.P, p = i - gs * g.P;
+            float s0 = 0.f, s1 = 0.f;
+            for (int cq = gs; cq < cqn; cq += L.Gs) {
+              const float4 a = xs[cq * PS + p];  // padding channels are 0 and stat(0) adds nothing
+              Meas<M>::stat(a.x, s0, s1);
+              Meas<M>::stat(a.y, s0, s1);
+              Meas<M>::stat(a.z, s0, s1);
+              Meas<M>::stat(a.w, s0, s1);
+            }
+            red[(gs * 2) * g.P + p] = s0;
+            red[(gs * 2 + 1) * g.P + p] = s1;
+          }
+          __syncthreads();
+          for (int i = t; i < 2 * g.P; i += T) {
+            const int k = i / g.P, p = i - k * g.P;
+            float s = st[k * PS + p];
+            for (int gs = 0; gs < L.Gs; ++gs) s += red[(gs * 2 + k) * g.P + p];
+            st[k * PS + p] = s;
+          }
+          __syncthreads();
+        }
+      }
+      if (ch == 0 && n0 == 0) NFP_STAMP(3);
+      if (active) {
+        for (int cq = cg; cq < cqn; cq += L.G) {
+          const float4* sl = xs + cq * PS;
+          const float4 a = sl[pcz];
+#pragma unroll
+          for (int j = 0; j < NN; ++j) {
+            const float4 bv = sl[q[j]];  // padding channels: term(0, 0) = 0 for every measure
+            acc[j] += (Meas<M>::term(a.x, bv.x, g) + Meas<M>::term(a.y, bv.y, g)) +
+                      (Meas<M>::term(a.z, bv.z, g) + Meas<M>::term(a.w, bv.w, g));
+          }
+        }
+      }
+    }
+    // combine the channel groups (fixed order), finalise, store
+    if (n0 == 0) NFP_STAMP(4);
+    __syncthreads();
+    if (active) {
+#pragma unroll
+      for (int j = 0; j < NN; ++j) red[(cg * NN + j) * L.Ot + ol] = acc[j];
+    }
+    __syncthreads();
+    // thread (output ol, neighbour row cg + k*rows): one division per thread for the whole kernel (ol, cg above)
+    if (ol < on) {
+      const int rows = T / L.Ot;
+      for (int j = cg; j < NN && n0 + j < g.N; j += rows) {
+        const int n = n0 + j;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;  // four interleaved partial sums, combined in a fixed order
+        int c2 = 0;
+        for (; c2 + 3 < L.G; c2 += 4) {
+          s0 += red[((c2 + 0) * NN + j) * L.Ot + ol];
+          s1 += red[((c2 + 1) * NN + j) * L.Ot + ol];
+          s2 += red[((c2 + 2) * NN + j) * L.Ot + ol];
+          s3 += red[((c2 + 3) * NN + j) * L.Ot + ol];
+        }
+        for (; c2 < L.G; ++c2) s0 += red[(c2 * NN + j) * L.Ot + ol];
+        const float s = (s0 + s1) + (s2 + s3);
+        const int qz = tap[n * L.Ot + ol];
+        const float v = Meas<M>::fin(s, st[pcz], st[PS + pcz], st[qz], st[PS + qz], g);
+        stx(out, ((long long)b * g.N + n) * g.O + o0 + ol, v, g.dtype);
+      }
+    }
+  }
+  NFP_STAMP(5);
+  if constexpr (NS > 0) {
+    if (saved != nullptr && blockIdx.y == 0) {  // per-input-pixel stats for backward, [B][NSTAT][P]
+      float* sv = saved + (long long)b * NS * g.P;
+      for (int p = t; p < g.P; p += T) {
+        sv[p] = Meas<M>::save0(st[p], st[PS + p], g) + (Pivot<M>::v ? piv[p] : 0.f);
+        if (NS > 1) sv[g.P + p] = Meas<M>::save1(st[p], st[PS + p], g);
+      }
+    }
+  }
 }
 
 }  // namespace nfp

@@ -121,8 +121,64 @@ int set_lds(K kernel, size_t bytes) {
 }
 
 // ---- generic launches -----------------------------------------------------------------------
+// Forward of nfp_gather.h (fwd_pairs): one workgroup per (image, tile of outputs); declines only when not even
+// one channel quad of the map fits next to its tables, then the chunked scalar kernel below serves the call.
+bool force_scalar_fwd() {
+  const char* e = getenv("NFP_FWD_SCALAR");
+  return e && e[0] == '1';
+}
+
+template <int M, int NN>
+int launch_fwd_pairs_t(const KP& g, const void* x, void* out, float* saved, hipStream_t st) {
+  constexpr int T = 512;
+  const int PS = g.P + 1, Q = (g.C + 3) / 4;
+  // output tiles: every CU busy at small batch, at most T outputs per tile
+  int tiles = (256 + g.B - 1) / g.B;
+  if (tiles > (g.O + 7) / 8) tiles = (g.O + 7) / 8;
+  if (tiles < (g.O + T - 1) / T) tiles = (g.O + T - 1) / T;
+  if (tiles < 1) tiles = 1;
+  PairsLds L;
+  L.Ot = (g.O + tiles - 1) / tiles;
+  tiles = (g.O + L.Ot - 1) / L.Ot;
+  L.G = T / L.Ot;
+  if (L.G > Q) L.G = Q;
+  L.Gs = T / g.P;
+  if (L.Gs > 16) L.Gs = 16;
+  if (L.Gs > Q) L.Gs = Q;
+  if (L.Gs < 1) L.Gs = 1;
+  long long w = 0;
+  L.st = (int)w;  w += 2LL * PS;
+  L.piv = (int)w; w += PS;
+  L.tap = (int)w; w += ((long long)(g.N + 1) * L.Ot + 1) / 2;
+  L.red = (int)w; w += std::max((long long)L.G * NN * L.Ot, 2LL * L.Gs * g.P);
+  w = (w + 3) & ~3LL;
+  L.xs = (int)w;
+  const long long quad_bytes = (long long)PS * 16, room = (long long)kLdsMax - w * 4;
+  if (room < quad_bytes) return kNotApplicable;
+  long long Cq = room / quad_bytes;
+  if (Cq > Q) Cq = Q;
+  if (Cq < Q) {  // several chunks: make them even
+    const long long nch = (Q + Cq - 1) / Cq;
+    Cq = (Q + nch - 1) / nch;
+  }
+  L.Cq = (int)Cq;
+  const size_t lds = (size_t)w * 4 + (size_t)Cq * quad_bytes;
+  if (int rc = set_lds(fwd_pairs<M, NN>, lds)) return rc;
+  hipLaunchKernelGGL((fwd_pairs<M, NN>), dim3(g.B, tiles), dim3(T), lds, st, g, L, x, out, saved);
+  g_launches++;
+  snprintf(g_variant, sizeof(g_variant), "fwd_pairs");
+  return hip_ok(hipGetLastError(), "launch fwd_pairs");
+}
+
+template <int M>
+int launch_fwd_pairs(const KP& g, const void* x, void* out, float* saved, hipStream_t st) {
+  if (force_scalar_fwd() || g.P > 65534) return kNotApplicable;
+  return g.N <= 8 ? launch_fwd_pairs_t<M, 8>(g, x, out, saved, st) : launch_fwd_pairs_t<M, 24>(g, x, out, saved, st);
+}
+
 template <int M>
 int launch_fwd_generic(KP g, const void* x, void* out, float* saved, hipStream_t st) {
+  if (int rc = launch_fwd_pairs<M>(g, x, out, saved, st); rc != kNotApplicable) return rc;
   g.Cc = kLdsBudgetFwd / (g.P * 4);
   if (g.Cc < 1) g.Cc = 1;
   if (g.Cc > g.C) g.Cc = g.C;
@@ -445,7 +501,10 @@ int nfp_forward(const nfp_desc* d, const void* x, void* out, float* saved, void*
   }
   switch (g.measure) {
     case NFP_COSINE: return launch_fwd_generic<NFP_COSINE>(g, x, out, saved, st);
-    case NFP_NORM: return launch_fwd_generic<NFP_NORM>(g, x, out, saved, st);
+    case NFP_NORM:
+      if (g.p == 1.f) return launch_fwd_generic<kNormP1>(g, x, out, saved, st);
+      if (g.p == 2.f) return launch_fwd_generic<kNormP2>(g, x, out, saved, st);
+      return launch_fwd_generic<NFP_NORM>(g, x, out, saved, st);
     case NFP_DOT: return launch_fwd_generic<NFP_DOT>(g, x, out, saved, st);
     case NFP_RMSE: return launch_fwd_generic<NFP_RMSE>(g, x, out, saved, st);
     case NFP_GEMAN: return launch_fwd_generic<NFP_GEMAN>(g, x, out, saved, st);
@@ -467,7 +526,7 @@ int nfp_forward(const nfp_desc* d, const void* x, void* out, float* saved, void*
       const long long n = (long long)g.B * g.O;
       hipLaunchKernelGGL(attn_softmax_fwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, g, out);
       g_launches++;
-      snprintf(g_variant, sizeof(g_variant), "fwd_generic+attn_softmax");
+      strncat(g_variant, "+attn_softmax", sizeof(g_variant) - strlen(g_variant) - 1);
       return hip_ok(hipGetLastError(), "launch attn_softmax_fwd");
     }
     default:
@@ -496,7 +555,10 @@ int nfp_backward(const nfp_desc* d, const void* x, const void* grad_out, const v
   }
   switch (g.measure) {
     case NFP_COSINE: return launch_bwd_generic<NFP_COSINE>(g, x, grad_out, out, saved, grad_x, st);
-    case NFP_NORM: return launch_bwd_generic<NFP_NORM>(g, x, grad_out, out, saved, grad_x, st);
+    case NFP_NORM:
+      if (g.p == 1.f) return launch_bwd_generic<kNormP1>(g, x, grad_out, out, saved, grad_x, st);
+      if (g.p == 2.f) return launch_bwd_generic<kNormP2>(g, x, grad_out, out, saved, grad_x, st);
+      return launch_bwd_generic<NFP_NORM>(g, x, grad_out, out, saved, grad_x, st);
     case NFP_DOT: return launch_bwd_generic<NFP_DOT>(g, x, grad_out, out, saved, grad_x, st);
     case NFP_RMSE: return launch_bwd_generic<NFP_RMSE>(g, x, grad_out, out, saved, grad_x, st);
     case NFP_GEMAN: return launch_bwd_generic<NFP_GEMAN>(g, x, grad_out, out, saved, grad_x, st);

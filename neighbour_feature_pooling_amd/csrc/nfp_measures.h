@@ -22,27 +22,31 @@ template <int M>
 struct Meas;
 
 // ---- Norm: -(sum |a-b|^p)^(1/p)   nfp.py:141-148 (weights nfp.py:74-80) -----------------
-template <>
-struct Meas<NFP_NORM> {
+// PK = 1 / 2: the order is known at compile time (the dispatcher picks these for p == 1, the reference's
+// default, and p == 2), so the per-channel code has no powf and no branch on p; PK = 0: any finite p > 0.
+template <int PK>
+struct MeasNorm {
   static constexpr int NSTAT = 0;
+  __device__ static __forceinline__ bool is1(const KP& g) { return PK == 1 || (PK == 0 && g.p == 1.f); }
+  __device__ static __forceinline__ bool is2(const KP& g) { return PK == 2 || (PK == 0 && g.p == 2.f); }
   __device__ static __forceinline__ float term(float a, float b, const KP& g) {
     float v = g.diff ? a - b : b;
-    if (g.p == 2.f) return v * v;
-    if (g.p == 1.f) return fabsf(v);
+    if (is2(g)) return v * v;
+    if (is1(g)) return fabsf(v);
     return powf(fabsf(v), g.p);
   }
   __device__ static __forceinline__ void stat(float, float&, float&) {}
   __device__ static __forceinline__ float fin(float acc, float, float, float, float, const KP& g) {
-    float d = g.p == 2.f ? sqrtf(acc) : (g.p == 1.f ? acc : powf(acc, 1.f / g.p));
+    float d = is2(g) ? sqrtf(acc) : (is1(g) ? acc : powf(acc, 1.f / g.p));
     return g.similarity ? -d : d;
   }
   __device__ static __forceinline__ Coef coef(float go, float outv, float, float, float, float, const KP& g) {
     float d = fabsf(outv);
     float sg = g.similarity ? -go : go;
     Coef c = {0.f, 0.f, 0.f, 0.f, 0.f};
-    if (g.p == 1.f)
+    if (is1(g))
       c.k0 = sg;
-    else if (g.p == 2.f)
+    else if (is2(g))
       c.k0 = d == 0.f ? 0.f : sg / d;
     else
       c.k0 = d == 0.f ? 0.f : sg / powf(d, g.p - 1.f);
@@ -51,9 +55,9 @@ struct Meas<NFP_NORM> {
   __device__ static __forceinline__ void grad(float a, float b, const Coef& c, const KP& g, float& da, float& db) {
     float v = g.diff ? a - b : b;
     float t;
-    if (g.p == 2.f)
+    if (is2(g))
       t = c.k0 * v;
-    else if (g.p == 1.f)
+    else if (is1(g))
       t = c.k0 * sgnf(v);
     else
       t = c.k0 * sgnf(v) * powf(fabsf(v), g.p - 1.f);
@@ -61,6 +65,13 @@ struct Meas<NFP_NORM> {
     db = g.diff ? -t : t;
   }
 };
+constexpr int kNormP1 = NFP_MEASURE_COUNT + 1, kNormP2 = NFP_MEASURE_COUNT + 2;  // internal dispatch ids
+template <>
+struct Meas<NFP_NORM> : MeasNorm<0> {};
+template <>
+struct Meas<kNormP1> : MeasNorm<1> {};
+template <>
+struct Meas<kNormP2> : MeasNorm<2> {};
 
 // ---- Cosine: sum (a/max(|a|,eps)) (b/max(|b|,eps))   nfp.py:150-159 ----------------------
 // Backward (torch 2.10 clamps the norms in place under NoGradGuard, so the

@@ -64,10 +64,12 @@ def _supported(c):
 @pytest.fixture(params=["auto", "generic", "atomic"])
 def variant(request, monkeypatch):
     """'auto' = the dispatcher's choice (hot-path kernels where they apply); 'generic' forces the
-    any-geometry kernels (gather-form backward); 'atomic' additionally forces the LDS-atomic backward that
-    serves maps too large for the gather tables — every implementation is held to the same bar on every case."""
+    any-geometry kernels of nfp_gather.h (fwd_pairs / bwd_gather); 'atomic' forces their fallbacks for maps
+    too large for those kernels' LDS tables (chunked scalar forward, LDS-atomic backward) — every
+    implementation is held to the same bar on every case."""
     monkeypatch.setenv("NFP_FORCE_GENERIC", "0" if request.param == "auto" else "1")
     monkeypatch.setenv("NFP_BWD_ATOMIC", "1" if request.param == "atomic" else "0")
+    monkeypatch.setenv("NFP_FWD_SCALAR", "1" if request.param == "atomic" else "0")
     return request.param
 
 
@@ -539,6 +541,7 @@ def test_gather_backward_geometry_sweep(B, C, H, W, R, pad, stride, dil, mode, m
     from neighbour_feature_pooling_amd._host import nfp_host
     monkeypatch.setenv("NFP_FORCE_GENERIC", "1")
     monkeypatch.setenv("NFP_BWD_ATOMIC", "0")
+    monkeypatch.setenv("NFP_FWD_SCALAR", "0")
     ctor = dict(R=R, measure=meas, padding=pad, stride=stride, dilation=dil, padding_mode=mode)
     if meas == "norm":
         ctor["p"] = 1
@@ -546,6 +549,8 @@ def test_gather_backward_geometry_sweep(B, C, H, W, R, pad, stride, dil, mode, m
     g = torch.Generator().manual_seed(H * 131 + W * 17 + C)
     x = (torch.rand(B, C, H, W, generator=g) + 0.25).to(dev).requires_grad_(True)   # positive: valid for every measure
     out = m(x)
+    assert _abi.load().nfp_last_variant().decode() == "fwd_pairs"
+    assert torch.equal(out, m(x))
     go = torch.randn(out.shape, generator=g).to(dev)
     gx, = torch.autograd.grad(out, x, go, retain_graph=True)
     assert _abi.load().nfp_last_variant().decode() == "bwd_gather"
@@ -557,6 +562,10 @@ def test_gather_backward_geometry_sweep(B, C, H, W, R, pad, stride, dil, mode, m
     assert rel_err(out.detach().cpu().numpy(), ref.detach().cpu().numpy()) <= TOL
     assert rel_err(gx.cpu().numpy(), gref.cpu().numpy()) <= 2 * TOL
     monkeypatch.setenv("NFP_BWD_ATOMIC", "1")
+    monkeypatch.setenv("NFP_FWD_SCALAR", "1")
     gx3, = torch.autograd.grad(out, x, go)
     assert _abi.load().nfp_last_variant().decode() == "bwd_generic"
     assert rel_err(gx3.cpu().numpy(), gref.cpu().numpy()) <= 2 * TOL
+    out3 = m(x)
+    assert _abi.load().nfp_last_variant().decode() == "fwd_generic"
+    assert rel_err(out3.detach().cpu().numpy(), ref.detach().cpu().numpy()) <= TOL
