@@ -66,8 +66,8 @@ __device__ __forceinline__ uint2 axis_reader(const KP& g, int i, int n, int no, 
 }
 
 
-// x[b, 4*qc0 : 4*(qc0+cqn), :, :] -> LDS float4[cq][PS] (PS = P + 1; pixel P of every quad is the zero a
-// zero-padded tap reads); any strides, f32 or bf16; channels past C are 0.  With a pivot table the slab
+// x[b, 4*qc0 : 4*(qc0+cqn), pixels p0 .. p0+np-1] -> LDS float4[cq][np + 1] (local pixel np of every quad is
+// the zero a zero-padded tap reads); any strides, f32 or bf16; channels past C are 0.  With a pivot table the slab
 // holds x - piv[pixel] (nfp_measures.h::Pivot), so padding channels and the zero pixel stay exact zeros.
 // The four loads of a quad are unconditional (addresses clamped into the tensor, surplus lanes zeroed
 // afterwards): a select or branch around a load makes hipcc wait for each one before issuing the next.
@@ -94,13 +94,17 @@ __device__ __forceinline__ float4 finish_quad(float4 v, int left, float pv) {
 }
 template <bool BF>
 __device__ __forceinline__ void stage_quads_t(float4* xs, const void* x, const KP& g, int b, int qc0, int cqn,
-                                              const float* piv) {
-  const int t = threadIdx.x, T = blockDim.x, PS = g.P + 1;
+                                              const float* piv, int p0, int np) {
+  const int t = threadIdx.x, T = blockDim.x, PS = np + 1;
+  if (np <= 0) {
+    for (int cq = t; cq < cqn; cq += T) xs[cq] = make_float4(0.f, 0.f, 0.f, 0.f);
+    return;
+  }
   // 2-D thread grid, fast axis = what is contiguous in memory: pixels (NCHW) or channel quads (channels-last);
   // one integer division per thread per call, two quads in flight per thread and iteration.
   const bool nhwc = g.sC == 1;
   const bool dense = g.sH == (long long)g.W * g.sW;  // pixel p sits at p * sW: no row / column split needed
-  const int nf = nhwc ? cqn : g.P, ns = nhwc ? g.P : cqn;
+  const int nf = nhwc ? cqn : np, ns = nhwc ? np : cqn;
   const int TF = min(nf, T), TS = T / TF;
   const int tf = t % TF, ts = t / TF;
   const long long img = (long long)b * g.sB;
@@ -117,10 +121,10 @@ __device__ __forceinline__ void stage_quads_t(float4* xs, const void* x, const K
           ps[u] = nhwc ? su : f;
           long long off;
           if (dense) {
-            off = (long long)ps[u] * g.sW;
+            off = (long long)(p0 + ps[u]) * g.sW;
           } else {
-            const int y = ps[u] / g.W;
-            off = (long long)y * g.sH + (long long)(ps[u] - y * g.W) * g.sW;
+            const int pg = p0 + ps[u], y = pg / g.W;
+            off = (long long)y * g.sH + (long long)(pg - y * g.W) * g.sW;
           }
           const int c = 4 * (qc0 + cqs[u]);
           lefts[u] = g.C - 1 - c;
@@ -134,14 +138,14 @@ __device__ __forceinline__ void stage_quads_t(float4* xs, const void* x, const K
       }
     }
   }
-  for (int cq = t; cq < cqn; cq += T) xs[cq * PS + g.P] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int cq = t; cq < cqn; cq += T) xs[cq * PS + np] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 __device__ __forceinline__ void stage_quads(float4* xs, const void* x, const KP& g, int b, int qc0, int cqn,
-                                            const float* piv = nullptr) {
+                                            const float* piv, int p0, int np) {
   if (g.dtype == NFP_F32)
-    stage_quads_t<false>(xs, x, g, b, qc0, cqn, piv);
+    stage_quads_t<false>(xs, x, g, b, qc0, cqn, piv, p0, np);
   else
-    stage_quads_t<true>(xs, x, g, b, qc0, cqn, piv);
+    stage_quads_t<true>(xs, x, g, b, qc0, cqn, piv, p0, np);
 }
 
 template <int M>
@@ -233,7 +237,7 @@ __global__ void __launch_bounds__(512) bwd_gather(const KP g, const GatherLds L,
     const int cqn = min(L.Cq, q_end - qc0);
     __syncthreads();  // tables complete, slots consumed / previous slab consumed
     if (qc0 == q_begin) NFP_STAMP(4);
-    stage_quads(xs, x, g, b, qc0, cqn);
+    stage_quads(xs, x, g, b, qc0, cqn, nullptr, 0, g.P);
     __syncthreads();
     if (qc0 == q_begin) NFP_STAMP(5);
     const int nqb = (cqn + QB - 1) / QB;
@@ -320,10 +324,12 @@ __global__ void __launch_bounds__(512) bwd_gather(const KP g, const GatherLds L,
 // needs per PIXEL (norms, means: Meas::stat) is summed once per pixel, not once per pair.
 struct PairsLds {
   int xs;    // float4 slab (word offset, multiple of 4)
-  int st;    // float [2][P + 1]  per-pixel stat sums (entry P = the zero pixel = 0)
-  int piv;   // float [P + 1]     per-pixel pivot (nfp_measures.h::Pivot), 0 where unused
-  int tap;   // u16   [N + 1][Ot] input pixel each tap of each output of the tile reads (row N = centre; P = zero)
+  int st;    // float [2][PSm]  per-pixel stat sums of the window (the zero pixel's entry = 0)
+  int piv;   // float [PSm]     per-pixel pivot (nfp_measures.h::Pivot), 0 where unused
+  int tap;   // u16   [N + 1][Ot] window pixel each tap of each output of the tile reads (row N = centre)
   int red;   // float scratch for the cross-group sums
+  int mm;    // int [2] min / max input pixel the tile reads
+  int PSm;   // bound on window pixels + 1 (the launcher's row-window bound)
   int Cq;    // channel quads per slab
   int Ot;    // outputs per workgroup tile
   int G;     // channel groups in the pair loop (G * Ot <= blockDim)
@@ -340,8 +346,9 @@ __global__ void __launch_bounds__(512) fwd_pairs(const KP g, const PairsLds L, c
   float* piv = lds + L.piv;
   unsigned short* tap = (unsigned short*)(lds + L.tap);
   float* red = lds + L.red;
+  int* mm = (int*)(lds + L.mm);
   const int b = blockIdx.x, t = threadIdx.x, T = blockDim.x;
-  const int PS = g.P + 1, Q = (g.C + 3) >> 2;
+  const int Q = (g.C + 3) >> 2;
   const int o0 = blockIdx.y * L.Ot, on = min(L.Ot, g.O - o0);
   const int ol = t % L.Ot, cg = t / L.Ot;
   const bool active = cg < L.G && ol < on;
@@ -349,24 +356,46 @@ __global__ void __launch_bounds__(512) fwd_pairs(const KP g, const PairsLds L, c
   NFP_STAMP_INIT();
   NFP_STAMP(0);
 
-  for (int i = t; i < 2 * PS; i += T) st[i] = 0.f;
-  for (int p = t; p < PS; p += T) {
-    float v = 0.f;
-    if (Pivot<M>::v && p < g.P) {
-      const int y = p / g.W, xx = p - y * g.W;
-      v = ldx(x, (long long)b * g.sB + (long long)y * g.sH + (long long)xx * g.sW, g.dtype);
-    }
-    piv[p] = v;
+  // ---- which input pixels does this tile of outputs read?  Only whole rows r0..r1 of x are staged. ------
+  if (t == 0) {
+    mm[0] = g.P;
+    mm[1] = -1;
   }
-  for (int i = t; i < L.Ot * g.k; i += T) {  // tap table of this tile: thread (output, kernel row) walks a row of taps
+  __syncthreads();
+  for (int i = t; i < L.Ot * g.k; i += T) {  // thread (output, kernel row) walks a row of taps
     const int ky = i / L.Ot, l = i - ky * L.Ot;
     const int oy = (o0 + l) / g.Wo, ox = (o0 + l) - oy * g.Wo, mid = (g.k * g.k) >> 1;
     const int yy = map_index(oy * g.stride + ky * g.dil - g.pad, g.H, g.mode);
+    int lo = g.P, hi = -1;
     for (int kx = 0, tp = ky * g.k; kx < g.k; ++kx, ++tp) {
       const int xx = map_index(ox * g.stride + kx * g.dil - g.pad, g.W, g.mode);
       const int px = (l < on && yy >= 0 && xx >= 0) ? yy * g.W + xx : g.P;
       tap[(tp == mid ? g.N : (tp < mid ? tp : tp - 1)) * L.Ot + l] = (unsigned short)px;
+      if (px < g.P) {
+        lo = min(lo, px);
+        hi = max(hi, px);
+      }
     }
+    if (hi >= 0) {
+      atomicMin(&mm[0], lo);
+      atomicMax(&mm[1], hi);
+    }
+  }
+  __syncthreads();
+  const int r0 = mm[1] < 0 ? 0 : mm[0] / g.W, r1 = mm[1] < 0 ? -1 : mm[1] / g.W;
+  const int p0 = r0 * g.W, np = (r1 - r0 + 1) * g.W, PS = np + 1;  // np + 1 <= L.PSm by the launcher's bound
+  for (int i = t; i < (g.N + 1) * L.Ot; i += T) {  // global pixel -> window pixel (np = the zero pixel)
+    const int px = tap[i];
+    tap[i] = (unsigned short)(px < g.P ? px - p0 : np);
+  }
+  for (int i = t; i < 2 * PS; i += T) st[i] = 0.f;
+  for (int p = t; p < PS; p += T) {
+    float v = 0.f;
+    if (Pivot<M>::v && p < np) {
+      const int pg = p0 + p, y = pg / g.W, xx = pg - y * g.W;
+      v = ldx(x, (long long)b * g.sB + (long long)y * g.sH + (long long)xx * g.sW, g.dtype);
+    }
+    piv[p] = v;
   }
   __syncthreads();
   const int pcz = tap[g.N * L.Ot + ol];
@@ -377,20 +406,20 @@ __global__ void __launch_bounds__(512) fwd_pairs(const KP g, const PairsLds L, c
 #pragma unroll
     for (int j = 0; j < NN; ++j) {
       acc[j] = 0.f;
-      q[j] = n0 + j < g.N ? (int)tap[(n0 + j) * L.Ot + ol] : g.P;
+      q[j] = n0 + j < g.N ? (int)tap[(n0 + j) * L.Ot + ol] : np;
     }
     for (int ch = 0; ch < nchunk; ++ch) {
       const int qc0 = ch * L.Cq, cqn = min(L.Cq, Q - qc0);
       if (n0 == 0 || nchunk > 1) {
         __syncthreads();  // previous slab consumed
         if (ch == 0 && n0 == 0) NFP_STAMP(1);
-        stage_quads(xs, x, g, b, qc0, cqn, Pivot<M>::v ? piv : nullptr);
+        stage_quads(xs, x, g, b, qc0, cqn, Pivot<M>::v ? piv : nullptr, p0, np);
         __syncthreads();
         if (ch == 0 && n0 == 0) NFP_STAMP(2);
         if (NS > 0 && n0 == 0) {
           // per-pixel stat sums of this chunk: thread (pixel, group) -> scratch -> st
-          for (int i = t; i < L.Gs * g.P; i += T) {
-            const int gs = i / g.P, p = i - gs * g.P;
+          for (int i = t; i < L.Gs * np; i += T) {
+            const int gs = i / np, p = i - gs * np;
             float s0 = 0.f, s1 = 0.f;
             for (int cq = gs; cq < cqn; cq += L.Gs) {
               const float4 a = xs[cq * PS + p];  // padding channels are 0 and stat(0) adds nothing
@@ -399,14 +428,14 @@ __global__ void __launch_bounds__(512) fwd_pairs(const KP g, const PairsLds L, c
               Meas<M>::stat(a.z, s0, s1);
               Meas<M>::stat(a.w, s0, s1);
             }
-            red[(gs * 2) * g.P + p] = s0;
-            red[(gs * 2 + 1) * g.P + p] = s1;
+            red[(gs * 2) * np + p] = s0;
+            red[(gs * 2 + 1) * np + p] = s1;
           }
           __syncthreads();
-          for (int i = t; i < 2 * g.P; i += T) {
-            const int k = i / g.P, p = i - k * g.P;
+          for (int i = t; i < 2 * np; i += T) {
+            const int k = i / np, p = i - k * np;
             float s = st[k * PS + p];
-            for (int gs = 0; gs < L.Gs; ++gs) s += red[(gs * 2 + k) * g.P + p];
+            for (int gs = 0; gs < L.Gs; ++gs) s += red[(gs * 2 + k) * np + p];
             st[k * PS + p] = s;
           }
           __syncthreads();
@@ -457,9 +486,11 @@ __global__ void __launch_bounds__(512) fwd_pairs(const KP g, const PairsLds L, c
   }
   NFP_STAMP(5);
   if constexpr (NS > 0) {
-    if (saved != nullptr && blockIdx.y == 0) {  // per-input-pixel stats for backward, [B][NSTAT][P]
-      float* sv = saved + (long long)b * NS * g.P;
-      for (int p = t; p < g.P; p += T) {
+    // per-input-pixel stats for backward, [B][NSTAT][P]: every tile stores the pixels of its window (tiles that
+    // share rows store identical values: the same channel order in every workgroup)
+    if (saved != nullptr) {
+      float* sv = saved + (long long)b * NS * g.P + p0;
+      for (int p = t; p < np; p += T) {
         sv[p] = Meas<M>::save0(st[p], st[PS + p], g) + (Pivot<M>::v ? piv[p] : 0.f);
         if (NS > 1) sv[g.P + p] = Meas<M>::save1(st[p], st[PS + p], g);
       }

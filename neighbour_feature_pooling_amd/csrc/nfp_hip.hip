@@ -131,29 +131,39 @@ bool force_scalar_fwd() {
 template <int M, int NN>
 int launch_fwd_pairs_t(const KP& g, const void* x, void* out, float* saved, hipStream_t st) {
   constexpr int T = 512;
-  const int PS = g.P + 1, Q = (g.C + 3) / 4;
-  // output tiles: every CU busy at small batch, at most T outputs per tile
+  const int Q = (g.C + 3) / 4;
+  // output tiles: every CU busy at small batch; at most T outputs per tile, whole output rows when there are
+  // several tiles per image anyway (a tile stages only the input rows it reads)
   int tiles = (256 + g.B - 1) / g.B;
   if (tiles > (g.O + 7) / 8) tiles = (g.O + 7) / 8;
-  if (tiles < (g.O + T - 1) / T) tiles = (g.O + T - 1) / T;
   if (tiles < 1) tiles = 1;
   PairsLds L;
   L.Ot = (g.O + tiles - 1) / tiles;
+  if (L.Ot > T) L.Ot = g.Wo <= T ? (T / g.Wo) * g.Wo : T;
   tiles = (g.O + L.Ot - 1) / L.Ot;
+  // rows of x a tile can read: its output rows through stride / dilation, plus what padding folds back in
+  // (inside that window when pad <= R*dilation; circular wraps and over-padding may reach anywhere)
+  int rows = g.H;
+  if (g.mode != NFP_PAD_CIRCULAR && g.pad <= g.R * g.dil) {
+    const int orows = std::min(g.Ho, (L.Ot + g.Wo - 2) / g.Wo + 1);  // a tile may start and end mid-row
+    rows = std::min(g.H, (orows - 1) * g.stride + 2 * g.R * g.dil + 1);
+  }
+  L.PSm = rows * g.W + 1;
   L.G = T / L.Ot;
   if (L.G > Q) L.G = Q;
-  L.Gs = T / g.P;
+  L.Gs = T / (L.PSm - 1);
   if (L.Gs > 16) L.Gs = 16;
   if (L.Gs > Q) L.Gs = Q;
   if (L.Gs < 1) L.Gs = 1;
   long long w = 0;
-  L.st = (int)w;  w += 2LL * PS;
-  L.piv = (int)w; w += PS;
+  L.st = (int)w;  w += 2LL * L.PSm;
+  L.piv = (int)w; w += L.PSm;
+  L.mm = (int)w;  w += 2;
   L.tap = (int)w; w += ((long long)(g.N + 1) * L.Ot + 1) / 2;
-  L.red = (int)w; w += std::max((long long)L.G * NN * L.Ot, 2LL * L.Gs * g.P);
+  L.red = (int)w; w += std::max((long long)L.G * NN * L.Ot, 2LL * L.Gs * (L.PSm - 1));
   w = (w + 3) & ~3LL;
   L.xs = (int)w;
-  const long long quad_bytes = (long long)PS * 16, room = (long long)kLdsMax - w * 4;
+  const long long quad_bytes = (long long)L.PSm * 16, room = (long long)kLdsMax - w * 4;
   if (room < quad_bytes) return kNotApplicable;
   long long Cq = room / quad_bytes;
   if (Cq > Q) Cq = Q;
