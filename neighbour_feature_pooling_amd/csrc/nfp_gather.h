@@ -315,6 +315,249 @@ __global__ void __launch_bounds__(512) bwd_gather(const KP g, const GatherLds L,
   NFP_STAMP(6);
 }
 
+// ---- the same backward for maps whose tables do not fit LDS whole: one workgroup per BAND of input rows ---
+// A band [ra, rb) of rows of grad_x needs: the reader lists of its rows (and of every column); the pair
+// table of the OUTPUT rows oya..oyb that read the band (local pair index j' = n*O' + o', O' = their count);
+// and the rows w0..w1 of x that those pairs pair the band with (the band itself, the centres of the outputs
+// that read it, the neighbours of the outputs centred in it).  All three ranges are found in LDS (min / max
+// over the lists and over the pairs), the launcher only bounds them: for non-circular padding with
+// pad <= R*dilation an output reads rows within R*dilation of its centre and padding folds back inside that
+// window, so oyb - oya + 1 <= (RB - 1 + 2*R*dil)/stride + 2 and w1 - w0 + 1 <= RB + 2*R*dil.
+struct BandLds {
+  int RB;          // input rows per band
+  int ONm;         // bound on N * O'
+  int cf, nbq;     // as GatherLds, sized for ONm
+  int yl, xl, yc, xc, capY, capX;  // row lists for RB rows, column lists for W columns
+  int mm;          // int [4]: min / max output row reading the band, min / max x row needed
+  int xs;          // float4 slab [Cq][PSm]; the raw reader slots live here until the first slab is staged
+  int PSm;         // bound on window pixels + 1
+  int Cq, Qwg;
+};
+
+// raw reader of axis coordinate i: {d | oa << 8, ca} or {0xFFFFFFFF, -}; ca = -1: centre in zero padding
+__device__ __forceinline__ uint2 axis_reader_raw(const KP& g, int i, int n, int no, int ic, int d) {
+  uint2 e = make_uint2(0xFFFFFFFFu, 0u);
+  const int tc = ic == 0 ? i : (ic <= g.pad ? -ic : n - 1 + (ic - g.pad));
+  if (ic > 0 && map_index(tc, n, g.mode) != i) return e;
+  const int nn = tc + g.pad - d * g.dil;
+  if (nn < 0) return e;
+  const int oa = g.stride == 1 ? nn : nn / g.stride;
+  if (oa * g.stride != nn || oa >= no) return e;
+  e.x = (unsigned)d | ((unsigned)oa << 8);
+  e.y = (unsigned)map_index(oa * g.stride + g.R * g.dil - g.pad, n, g.mode);
+  return e;
+}
+
+template <int M, int QB>
+__global__ void __launch_bounds__(512) bwd_gather_banded(const KP g, const BandLds L, const void* __restrict__ x,
+                                                         const void* __restrict__ go, const void* __restrict__ out,
+                                                         const float* __restrict__ saved, void* __restrict__ gx) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int NC = NCoef<M>::v;
+  float* cf = lds + L.cf;
+  unsigned short* nbq = (unsigned short*)(lds + L.nbq);
+  uint2* yl = (uint2*)(lds + L.yl);
+  uint2* xl = (uint2*)(lds + L.xl);
+  unsigned* yc = (unsigned*)(lds + L.yc);
+  unsigned* xc = (unsigned*)(lds + L.xc);
+  int* mm = (int*)(lds + L.mm);
+  float4* xs = (float4*)(lds + L.xs);
+  const int b = blockIdx.x, t = threadIdx.x, T = blockDim.x;
+  const int ra = blockIdx.z * L.RB, rb = min(g.H, ra + L.RB), nr = rb - ra;  // this band's rows
+  const float* sv = (Meas<M>::NSTAT > 0) ? saved + (long long)b * Meas<M>::NSTAT * g.P : nullptr;
+
+  if (t == 0) {
+    mm[0] = g.Ho;
+    mm[1] = -1;
+    mm[2] = ra;        // the band itself is part of the window
+    mm[3] = rb - 1;
+  }
+  __syncthreads();
+  // ---- raw reader slots of the band's rows and of every column; which output rows read the band? --------
+  const int nslot = (2 * g.pad + 1) * g.k;
+  uint2* slots = (uint2*)xs;
+  for (int s = t; s < (nr + g.W) * nslot; s += T) {
+    const int i = s / nslot, w = s - i * nslot, ic = w / g.k, d = w - ic * g.k;
+    uint2 e;
+    if (i < nr) {
+      e = axis_reader_raw(g, ra + i, g.H, g.Ho, ic, d);
+      if (e.x != 0xFFFFFFFFu) {
+        const int oa = (int)(e.x >> 8), ca = (int)e.y;
+        atomicMin(&mm[0], oa);
+        atomicMax(&mm[1], oa);
+        if (ca >= 0) {  // the centre row of an output that reads the band
+          atomicMin(&mm[2], ca);
+          atomicMax(&mm[3], ca);
+        }
+      }
+    } else {
+      e = axis_reader_raw(g, i - nr, g.W, g.Wo, ic, d);
+    }
+    slots[s] = e;
+  }
+  __syncthreads();
+  const int oya = mm[0], oyb = mm[1];
+  const int Ol = oyb < oya ? 0 : (oyb - oya + 1) * g.Wo, ON = Ol * g.N;  // local outputs and pairs (<= L.ONm)
+  const int o_base = oya * g.Wo;
+  // ---- which rows of x do the outputs centred in the band pair it with? -----------------------------------
+  for (int j = t; j < ON; j += T) {
+    const int n = j / Ol, o = o_base + (j - n * Ol);
+    const int pc = tap_pixel(g, o, g.R, g.R);
+    if (pc >= ra * g.W && pc < rb * g.W) {
+      const int q = nbr_pixel(g, o, n);
+      if (q >= 0) {
+        atomicMin(&mm[2], q / g.W);
+        atomicMax(&mm[3], q / g.W);
+      }
+    }
+  }
+  __syncthreads();
+  const int w0 = mm[2], w1 = mm[3];
+  const int p0 = w0 * g.W, np = (w1 - w0 + 1) * g.W, PS = np + 1;  // window pixels (np + 1 <= L.PSm)
+  if (ON > L.ONm || PS > L.PSm) {
+    // cannot happen if the launcher's bounds hold; never write past LDS: poison this band's gradient instead
+    const int Q0 = (g.C + 3) >> 2, qa = blockIdx.y * L.Qwg, qe = min(Q0, qa + L.Qwg);
+    for (int i = t; i < (qe - qa) * 4 * nr * g.W; i += T) {
+      const int c = 4 * qa + i / (nr * g.W), rl = i % (nr * g.W);
+      if (c < g.C)
+        stx(gx, (long long)b * g.sB + (long long)c * g.sC + (long long)(ra + rl / g.W) * g.sH +
+                (long long)(rl % g.W) * g.sW, __builtin_nanf(""), g.dtype);
+    }
+    return;
+  }
+  // ---- final tables -------------------------------------------------------------------------------------------
+  for (int i = t; i < nr + g.W; i += T) {
+    const bool rows = i < nr;
+    uint2* list = rows ? yl + i * L.capY : xl + (i - nr) * L.capX;
+    const unsigned cd = (unsigned)g.R;
+    unsigned cnt = 0, ncentre = 0;
+    for (int pass = 0; pass < 2; ++pass) {  // readers through the centre tap first, then the others, in slot order
+      for (int w = 0; w < nslot; ++w) {
+        const uint2 e = slots[i * nslot + w];
+        if (e.x == 0xFFFFFFFFu) continue;
+        const unsigned d = e.x & 0xFFu;
+        if ((d == cd) != (pass == 0)) continue;
+        const int oa = (int)(e.x >> 8), ca = (int)e.y;
+        uint2 f;
+        if (rows) {
+          f.x = (unsigned)((int)d * g.k * Ol + (oa - oya) * g.Wo);
+          f.y = (ca < 0 ? kNoCentre : (unsigned)((ca - w0) * g.W)) | ((d * (unsigned)g.k) << 20);
+        } else {
+          f.x = (unsigned)((int)d * Ol + oa);
+          f.y = (ca < 0 ? kNoCentre : (unsigned)ca) | (d << 20);
+        }
+        list[cnt++] = f;
+      }
+      if (pass == 0) ncentre = cnt;
+    }
+    if (rows)
+      yc[i] = cnt | (ncentre << 16);
+    else
+      xc[i - nr] = cnt | (ncentre << 16);
+  }
+  for (int j = t; j < ON; j += T) {
+    const int n = j / Ol, o = o_base + (j - n * Ol);
+    const int q = nbr_pixel(g, o, n), pc = tap_pixel(g, o, g.R, g.R);
+    const long long oi = ((long long)b * g.N + n) * g.O + o;
+    const float sp0 = (Meas<M>::NSTAT > 0 && pc >= 0) ? sv[pc] : 0.f;
+    const float sp1 = (Meas<M>::NSTAT > 1 && pc >= 0) ? sv[g.P + pc] : 0.f;
+    const float sq0 = (Meas<M>::NSTAT > 0 && q >= 0) ? sv[q] : 0.f;
+    const float sq1 = (Meas<M>::NSTAT > 1 && q >= 0) ? sv[g.P + q] : 0.f;
+    const Coef c = Meas<M>::coef(ldx(go, oi, g.godtype), ldx(out, oi, g.dtype), sp0, sp1, sq0, sq1, g);
+    cf[j] = c.k0;
+    if (NC > 1) cf[ON + j] = c.k1;
+    if (NC > 2) cf[2 * ON + j] = c.k2;
+    if (NC > 3) cf[3 * ON + j] = c.k3;
+    if (NC > 4) cf[4 * ON + j] = c.k4;
+    // neighbour pixel in window coordinates; read only for outputs centred in the band, whose neighbours are
+    // inside the window by construction (anything else, and zero padding, -> the zero pixel)
+    const int ql = q - p0;
+    nbq[j] = (unsigned short)((q < 0 || ql < 0 || ql >= np) ? np : ql);
+  }
+
+  // ---- channel loop ------------------------------------------------------------------------------------
+  const int Q = (g.C + 3) >> 2;
+  const int q_begin = blockIdx.y * L.Qwg, q_end = min(Q, q_begin + L.Qwg);
+  const unsigned mid = (unsigned)((g.k * g.k) >> 1);
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int nbp = nr * g.W;  // band pixels
+  for (int qc0 = q_begin; qc0 < q_end; qc0 += L.Cq) {
+    const int cqn = min(L.Cq, q_end - qc0);
+    __syncthreads();  // tables complete, slots consumed / previous slab consumed
+    stage_quads(xs, x, g, b, qc0, cqn, nullptr, p0, np);
+    __syncthreads();
+    const int nqb = (cqn + QB - 1) / QB;
+    for (int i = t; i < nqb * nbp; i += T) {
+      const int qb = i / nbp, rl = i - qb * nbp;
+      const int ryl = rl / g.W, rx = rl - ryl * g.W, ry = ra + ryl;
+      const int r = (ry - w0) * g.W + rx;  // window pixel of this band pixel
+      const float4* slab[QB];
+      float4 a[QB], acc[QB];
+#pragma unroll
+      for (int u = 0; u < QB; ++u) {
+        slab[u] = xs + min(qb * QB + u, cqn - 1) * PS;
+        a[u] = slab[u][r];
+        acc[u] = zero4;
+      }
+      const uint2* yrow = yl + ryl * L.capY;
+      const uint2* xrow = xl + rx * L.capX;
+      const unsigned ycw = yc[ryl], xcw = xc[rx];
+      const unsigned ny = ycw & 0xFFFFu, nx = xcw & 0xFFFFu, nyc = ycw >> 16, nxc = xcw >> 16;
+      for (unsigned iy = 0; iy < nyc; ++iy) {  // centre role
+        const uint2 ey = yrow[iy];
+        for (unsigned ix = 0; ix < nxc; ++ix) {
+          const uint2 ex = xrow[ix];
+          for (int n = 0, j = (int)(ey.x + ex.x) - (int)mid * Ol; n < g.N; ++n, j += Ol) {
+            const unsigned q = nbq[j];
+            const Coef c = load_coef<M>(cf, ON, j);
+#pragma unroll
+            for (int u = 0; u < QB; ++u) {
+              const float4 bv = slab[u][q];
+              float da, db;
+              Meas<M>::grad(a[u].x, bv.x, c, g, da, db); acc[u].x += da;
+              Meas<M>::grad(a[u].y, bv.y, c, g, da, db); acc[u].y += da;
+              Meas<M>::grad(a[u].z, bv.z, c, g, da, db); acc[u].z += da;
+              Meas<M>::grad(a[u].w, bv.w, c, g, da, db); acc[u].w += da;
+            }
+          }
+        }
+      }
+      for (unsigned iy = 0; iy < ny; ++iy) {  // neighbour role
+        const uint2 ey = yrow[iy];
+        for (unsigned ix = 0; ix < nx; ++ix) {
+          if (iy < nyc && ix < nxc) continue;
+          const uint2 ex = xrow[ix];
+          const unsigned tap = (ey.y >> 20) + (ex.y >> 20);
+          const int j = (int)(ey.x + ex.x) - (tap > mid ? Ol : 0);
+          const unsigned pc = min((ey.y & 0xFFFFFu) + (ex.y & 0xFFFFFu), (unsigned)np);
+          const Coef c = load_coef<M>(cf, ON, j);
+#pragma unroll
+          for (int u = 0; u < QB; ++u) {
+            const float4 av = slab[u][pc];
+            float da, db;
+            Meas<M>::grad(av.x, a[u].x, c, g, da, db); acc[u].x += db;
+            Meas<M>::grad(av.y, a[u].y, c, g, da, db); acc[u].y += db;
+            Meas<M>::grad(av.z, a[u].z, c, g, da, db); acc[u].z += db;
+            Meas<M>::grad(av.w, a[u].w, c, g, da, db); acc[u].w += db;
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < QB; ++u) {
+        const int cq = qb * QB + u;
+        if (cq < cqn) {
+          const int c = 4 * (qc0 + cq);
+          const long long base = (long long)b * g.sB + (long long)c * g.sC + (long long)ry * g.sH + (long long)rx * g.sW;
+          stx(gx, base, acc[u].x, g.dtype);
+          if (c + 1 < g.C) stx(gx, base + g.sC, acc[u].y, g.dtype);
+          if (c + 2 < g.C) stx(gx, base + 2 * g.sC, acc[u].z, g.dtype);
+          if (c + 3 < g.C) stx(gx, base + 3 * g.sC, acc[u].w, g.dtype);
+        }
+      }
+    }
+  }
+}
+
 // ---- forward --------------------------------------------------------------------------------------------
 // Replaces nfp.py:132-159 (pad -> two frozen depthwise convs -> view -> measure over C) for every measure
 // and geometry.  One workgroup = one image x one tile of outputs.  x is staged once per channel chunk into

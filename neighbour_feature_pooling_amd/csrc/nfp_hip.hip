@@ -218,6 +218,10 @@ bool force_atomic() {
   const char* e = getenv("NFP_BWD_ATOMIC");
   return e && e[0] == '1';
 }
+int force_bands() {  // tests: NFP_BWD_BANDS=n sends every call through the banded kernel with >= n bands
+  const char* e = getenv("NFP_BWD_BANDS");
+  return e ? atoi(e) : 0;
+}
 
 #ifndef NFP_GATHER_WGS
 #define NFP_GATHER_WGS 512
@@ -235,7 +239,8 @@ int launch_bwd_gather(const KP& g, const void* x, const void* go, const void* ou
   constexpr int QB = NFP_GATHER_QB, NC = NCoef<M>::v;
   const long long ON = (long long)g.O * g.N;
   // index ranges the packed tables hold (nfp_gather.h)
-  if (force_atomic() || ON > 65535 || g.P > 65534 || g.k > 15 || g.pad > 8 || g.H >= 16383 || g.W >= 16383)
+  if (force_atomic() || force_bands() > 0 || ON > 65535 || g.P > 65534 || g.k > 15 || g.pad > 8 || g.H >= 16383 ||
+      g.W >= 16383)
     return kNotApplicable;
   auto folds = [&](int n) {  // padded coordinates that can fold onto one coordinate of an axis of size n
     if (g.pad == 0 || g.mode == NFP_PAD_ZEROS) return 1;
@@ -284,10 +289,79 @@ int launch_bwd_gather(const KP& g, const void* x, const void* go, const void* ou
   return hip_ok(hipGetLastError(), "launch bwd_gather");
 }
 
+// Banded variant for maps whose whole-image tables exceed LDS (nfp_gather.h::bwd_gather_banded).
+template <int M>
+int launch_bwd_gather_banded(const KP& g, const void* x, const void* go, const void* out, const float* saved,
+                             void* gx, hipStream_t st) {
+  constexpr int QB = NFP_GATHER_QB, NC = NCoef<M>::v;
+  if (force_atomic() || g.k > 15 || g.pad > 8 || g.H >= 16383 || g.W >= 16383) return kNotApplicable;
+  auto folds = [&](int n) {
+    if (g.pad == 0 || g.mode == NFP_PAD_ZEROS) return 1;
+    if (g.mode == NFP_PAD_REPLICATE) return n == 1 ? 2 * g.pad + 1 : g.pad + 1;
+    return 3;
+  };
+  const bool local = g.mode != NFP_PAD_CIRCULAR && g.pad <= g.R * g.dil;  // an output reads near its centre only
+  const int reach = 2 * g.R * g.dil, nslot = (2 * g.pad + 1) * g.k, Q = (g.C + 3) / 4;
+  BandLds L;
+  L.capY = g.k * folds(g.H);
+  L.capX = g.k * folds(g.W);
+  long long w = 0;
+  size_t table_bytes = 0, quad_bytes = 0, slot_bytes = 0;
+  int bands = 0;
+  const int nb0 = local ? std::min(std::max(force_bands(), 1), g.H) : 1;
+  for (int nb = nb0; nb <= g.H; nb = local ? nb + 1 : g.H + 1) {
+    const int RB = (g.H + nb - 1) / nb;
+    const int orows = local ? std::min(g.Ho, (RB - 1 + reach) / g.stride + 2) : g.Ho;
+    const int wrows = local ? std::min(g.H, RB + reach) : g.H;
+    const long long ONm = (long long)g.N * orows * g.Wo, PSm = (long long)wrows * g.W + 1;
+    if (PSm > 65535) continue;
+    w = 0;
+    L.cf = (int)w;  w += NC * ONm;
+    L.nbq = (int)w; w += (ONm + 1) / 2;
+    w = (w + 1) & ~1LL;
+    L.yl = (int)w;  w += 2LL * RB * L.capY;
+    L.xl = (int)w;  w += 2LL * g.W * L.capX;
+    L.yc = (int)w;  w += RB;
+    L.xc = (int)w;  w += g.W;
+    L.mm = (int)w;  w += 4;
+    w = (w + 3) & ~3LL;
+    table_bytes = (size_t)w * 4;
+    quad_bytes = (size_t)PSm * 16;
+    slot_bytes = (size_t)(RB + g.W) * nslot * 8;
+    // tables may take half of LDS; the rest is the slab (at least one block of QB quads) or the slots
+    if (table_bytes <= (size_t)kLdsMax / 2 && table_bytes + std::max(QB * quad_bytes, slot_bytes) <= (size_t)kLdsMax) {
+      L.RB = RB;
+      L.ONm = (int)ONm;
+      L.PSm = (int)PSm;
+      L.xs = (int)w;
+      bands = (g.H + RB - 1) / RB;
+      break;
+    }
+  }
+  if (bands == 0) return kNotApplicable;
+  int S = (NFP_GATHER_WGS + g.B * bands - 1) / (g.B * bands);
+  const int maxS = (Q + QB - 1) / QB;
+  if (S > maxS) S = maxS;
+  if (S < 1) S = 1;
+  L.Qwg = (((Q + S - 1) / S) + QB - 1) / QB * QB;
+  S = (Q + L.Qwg - 1) / L.Qwg;
+  size_t room = (size_t)kLdsMax - table_bytes;
+  int Cq = (int)(room / quad_bytes) / QB * QB;
+  if (Cq > L.Qwg) Cq = L.Qwg;
+  L.Cq = Cq;
+  const size_t lds = table_bytes + std::max((size_t)Cq * quad_bytes, slot_bytes);
+  if (int rc = set_lds(bwd_gather_banded<M, QB>, lds)) return rc;
+  hipLaunchKernelGGL((bwd_gather_banded<M, QB>), dim3(g.B, S, bands), dim3(512), lds, st, g, L, x, go, out, saved, gx);
+  g_launches++;
+  snprintf(g_variant, sizeof(g_variant), "bwd_gather_banded");
+  return hip_ok(hipGetLastError(), "launch bwd_gather_banded");
+}
+
 template <int M>
 int launch_bwd_generic(KP g, const void* x, const void* go, const void* out, const float* saved, void* gx,
                        hipStream_t st) {
   if (int rc = launch_bwd_gather<M>(g, x, go, out, saved, gx, st); rc != kNotApplicable) return rc;
+  if (int rc = launch_bwd_gather_banded<M>(g, x, go, out, saved, gx, st); rc != kNotApplicable) return rc;
   g.Cc = kLdsBudgetBwd / (g.P * 4);
   if (g.Cc < 1) g.Cc = 1;
   if (g.Cc > g.C) g.Cc = g.C;

@@ -70,6 +70,7 @@ def variant(request, monkeypatch):
     monkeypatch.setenv("NFP_FORCE_GENERIC", "0" if request.param == "auto" else "1")
     monkeypatch.setenv("NFP_BWD_ATOMIC", "1" if request.param == "atomic" else "0")
     monkeypatch.setenv("NFP_FWD_SCALAR", "1" if request.param == "atomic" else "0")
+    monkeypatch.delenv("NFP_BWD_BANDS", raising=False)
     return request.param
 
 
@@ -561,6 +562,12 @@ def test_gather_backward_geometry_sweep(B, C, H, W, R, pad, stride, dil, mode, m
     gref, = torch.autograd.grad(ref, x64, go.double())
     assert rel_err(out.detach().cpu().numpy(), ref.detach().cpu().numpy()) <= TOL
     assert rel_err(gx.cpu().numpy(), gref.cpu().numpy()) <= 2 * TOL
+    # the banded kernel (maps too large for whole-image tables), forced here onto 3 bands of rows
+    monkeypatch.setenv("NFP_BWD_BANDS", "3")
+    gxb, = torch.autograd.grad(out, x, go, retain_graph=True)
+    assert _abi.load().nfp_last_variant().decode() in ("bwd_gather_banded", "bwd_generic")
+    assert rel_err(gxb.cpu().numpy(), gref.cpu().numpy()) <= 2 * TOL
+    monkeypatch.delenv("NFP_BWD_BANDS")
     monkeypatch.setenv("NFP_BWD_ATOMIC", "1")
     monkeypatch.setenv("NFP_FWD_SCALAR", "1")
     gx3, = torch.autograd.grad(out, x, go)
@@ -569,3 +576,31 @@ def test_gather_backward_geometry_sweep(B, C, H, W, R, pad, stride, dil, mode, m
     out3 = m(x)
     assert _abi.load().nfp_last_variant().decode() == "fwd_generic"
     assert rel_err(out3.detach().cpu().numpy(), ref.detach().cpu().numpy()) <= TOL
+
+
+@pytest.mark.parametrize("B,C,H,W,ctor", [
+    (2, 12, 60, 52, dict(R=1, measure="cosine", padding=1)),
+    (1, 7, 75, 41, dict(R=2, measure="norm", p=1, padding=2, padding_mode="replicate")),
+    (2, 8, 64, 64, dict(R=1, measure="canberra", padding=1, stride=2, padding_mode="zeros")),
+    (1, 6, 90, 33, dict(R=1, measure="pearson", padding=2, dilation=2)),
+    (3, 64, 56, 56, dict(R=1, measure="cosine", padding=1)),
+])
+def test_large_maps_use_the_banded_backward(B, C, H, W, ctor, dev):
+    """Maps whose whole-image pair tables exceed LDS: row-windowed forward tiles, row-banded gather backward."""
+    from neighbour_feature_pooling_amd import NFPPooling, _abi
+    from neighbour_feature_pooling_amd._host import nfp_host
+    m = NFPPooling(C, **ctor)
+    g = torch.Generator().manual_seed(H + W)
+    x = (torch.rand(B, C, H, W, generator=g) + 0.25).to(dev).requires_grad_(True)
+    out = m(x)
+    assert _abi.load().nfp_last_variant().decode() == "fwd_pairs"
+    go = torch.randn(out.shape, generator=g).to(dev)
+    gx, = torch.autograd.grad(out, x, go, retain_graph=True)
+    assert _abi.load().nfp_last_variant().decode() == "bwd_gather_banded"
+    gx2, = torch.autograd.grad(out, x, go)
+    assert torch.equal(gx, gx2)
+    x64 = x.detach().double().requires_grad_(True)
+    ref = nfp_host(x64, m.config)
+    gref, = torch.autograd.grad(ref, x64, go.double())
+    assert rel_err(out.detach().cpu().numpy(), ref.detach().cpu().numpy()) <= TOL
+    assert rel_err(gx.cpu().numpy(), gref.cpu().numpy()) <= 2 * TOL
