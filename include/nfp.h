@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define NFP_ABI_VERSION 2
+#define NFP_ABI_VERSION 3
 
 /* error codes */
 #define NFP_OK 0
@@ -127,6 +127,16 @@ uint64_t nfp_launch_count(void);
 /* Name of the kernel variant the last nfp_forward / nfp_backward of this
  * process selected (for bench / profile bookkeeping). */
 const char* nfp_last_variant(void);
+
+/* Describe, WITHOUT touching the GPU, what nfp_forward (backward = 0) or
+ * nfp_backward (backward != 0) would launch for `d` with 4 KiB-aligned buffers:
+ *   "<variant> | <kernel> grid=(x,y,z) block=t lds=bytes[; <kernel> ...]"
+ * written NUL-terminated into buf.  Returns what the real call would return for
+ * the descriptor (NFP_E_UNSUPPORTED / NFP_E_INVALID with nfp_last_error set).
+ * No reference counterpart: lets the dispatch rules (which kernel serves which
+ * geometry, every launch within the device's LDS / grid limits) be tested on a
+ * machine without a GPU. */
+int nfp_plan(const nfp_desc* d, int32_t backward, char* buf, int32_t buflen);
 
 #ifdef __cplusplus
 }

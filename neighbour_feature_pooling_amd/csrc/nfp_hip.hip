@@ -120,6 +120,30 @@ int set_lds(K kernel, size_t bytes) {
   return NFP_OK;
 }
 
+// One way to launch: host-side limits first (a launch the hardware would refuse or fault on is never
+// attempted), then the LDS opt-in, the launch and its error.  In plan mode (nfp_plan) nothing touches the
+// GPU: the launch is only described, so the dispatcher's decisions are testable without a device.
+thread_local bool t_dry = false;
+thread_local char t_plan[512] = "";
+
+template <typename K, typename... A>
+int launch(const char* name, K kernel, dim3 grid, dim3 block, size_t lds, hipStream_t st, A... args) {
+  if (lds > (size_t)kLdsMax || block.x < 1 || block.x > 1024 || grid.x < 1 || grid.y < 1 || grid.z < 1 ||
+      grid.y > 65535 || grid.z > 65535)
+    return fail(NFP_E_UNSUPPORTED, "%s: launch shape grid (%u,%u,%u) block %u lds %zu outside the device limits", name,
+                grid.x, grid.y, grid.z, block.x, lds);
+  if (t_dry) {
+    const size_t n = strlen(t_plan);
+    snprintf(t_plan + n, sizeof(t_plan) - n, "%s%s grid=(%u,%u,%u) block=%u lds=%zu", n ? "; " : "", name, grid.x, grid.y,
+             grid.z, block.x, lds);
+    return NFP_OK;
+  }
+  if (int rc = set_lds(kernel, lds)) return rc;
+  hipLaunchKernelGGL(kernel, grid, block, lds, st, args...);
+  g_launches++;
+  return hip_ok(hipGetLastError(), name);
+}
+
 // ---- generic launches -----------------------------------------------------------------------
 // Forward of nfp_gather.h (fwd_pairs): one workgroup per (image, tile of outputs); declines only when not even
 // one channel quad of the map fits next to its tables, then the chunked scalar kernel below serves the call.
@@ -173,11 +197,8 @@ int launch_fwd_pairs_t(const KP& g, const void* x, void* out, float* saved, hipS
   }
   L.Cq = (int)Cq;
   const size_t lds = (size_t)w * 4 + (size_t)Cq * quad_bytes;
-  if (int rc = set_lds(fwd_pairs<M, NN>, lds)) return rc;
-  hipLaunchKernelGGL((fwd_pairs<M, NN>), dim3(g.B, tiles), dim3(T), lds, st, g, L, x, out, saved);
-  g_launches++;
   snprintf(g_variant, sizeof(g_variant), "fwd_pairs");
-  return hip_ok(hipGetLastError(), "launch fwd_pairs");
+  return launch("fwd_pairs", fwd_pairs<M, NN>, dim3(g.B, tiles), dim3(T), lds, st, g, L, x, out, saved);
 }
 
 template <int M>
@@ -204,12 +225,9 @@ int launch_fwd_generic(KP g, const void* x, void* out, float* saved, hipStream_t
   int T = ((g.Ow * g.G + 63) / 64) * 64;
   size_t lds = (size_t)g.Cc * g.P * 4;
   if (lds > (size_t)kLdsMax) return fail(NFP_E_UNSUPPORTED, "forward: feature map %dx%d does not fit LDS", g.H, g.W);
-  if (int rc = set_lds(fwd_generic<M>, lds)) return rc;
   dim3 grid(g.B, (g.O + g.Ow - 1) / g.Ow, (g.N + kGroup - 1) / kGroup);
-  hipLaunchKernelGGL(fwd_generic<M>, grid, dim3(T), lds, st, g, x, out, saved);
-  g_launches++;
   snprintf(g_variant, sizeof(g_variant), "fwd_generic");
-  return hip_ok(hipGetLastError(), "launch fwd_generic");
+  return launch("fwd_generic", fwd_generic<M>, grid, dim3(T), lds, st, g, x, out, saved);
 }
 
 // Gather-form backward (nfp_gather.h): tables + one slab of >= QB channel quads must fit in LDS and the
@@ -282,11 +300,8 @@ int launch_bwd_gather(const KP& g, const void* x, const void* go, const void* ou
   if (Cq > L.Qwg) Cq = L.Qwg;
   L.Cq = Cq;
   const size_t lds = table_bytes + std::max((size_t)Cq * quad_bytes, slot_bytes);
-  if (int rc = set_lds(bwd_gather<M, QB>, lds)) return rc;
-  hipLaunchKernelGGL((bwd_gather<M, QB>), dim3(g.B, S), dim3(512), lds, st, g, L, x, go, out, saved, gx);
-  g_launches++;
   snprintf(g_variant, sizeof(g_variant), "bwd_gather");
-  return hip_ok(hipGetLastError(), "launch bwd_gather");
+  return launch("bwd_gather", bwd_gather<M, QB>, dim3(g.B, S), dim3(512), lds, st, g, L, x, go, out, saved, gx);
 }
 
 // Banded variant for maps whose whole-image tables exceed LDS (nfp_gather.h::bwd_gather_banded).
@@ -350,11 +365,9 @@ int launch_bwd_gather_banded(const KP& g, const void* x, const void* go, const v
   if (Cq > L.Qwg) Cq = L.Qwg;
   L.Cq = Cq;
   const size_t lds = table_bytes + std::max((size_t)Cq * quad_bytes, slot_bytes);
-  if (int rc = set_lds(bwd_gather_banded<M, QB>, lds)) return rc;
-  hipLaunchKernelGGL((bwd_gather_banded<M, QB>), dim3(g.B, S, bands), dim3(512), lds, st, g, L, x, go, out, saved, gx);
-  g_launches++;
   snprintf(g_variant, sizeof(g_variant), "bwd_gather_banded");
-  return hip_ok(hipGetLastError(), "launch bwd_gather_banded");
+  return launch("bwd_gather_banded", bwd_gather_banded<M, QB>, dim3(g.B, S, bands), dim3(512), lds, st, g, L, x, go, out,
+                saved, gx);
 }
 
 template <int M>
@@ -382,12 +395,9 @@ int launch_bwd_generic(KP g, const void* x, const void* go, const void* out, con
   if (lds > (size_t)kLdsMax)
     return fail(NFP_E_UNSUPPORTED, "backward: feature map %dx%d needs %zu B of LDS for one channel (x + grad slabs), "
                 "limit %d", g.H, g.W, lds, kLdsMax);
-  if (int rc = set_lds(bwd_generic<M>, lds)) return rc;
   dim3 grid(g.B, (g.C + g.Cwg - 1) / g.Cwg);
-  hipLaunchKernelGGL(bwd_generic<M>, grid, dim3(T), lds, st, g, x, go, out, saved, gx);
-  g_launches++;
   snprintf(g_variant, sizeof(g_variant), "bwd_generic");
-  return hip_ok(hipGetLastError(), "launch bwd_generic");
+  return launch("bwd_generic", bwd_generic<M>, grid, dim3(T), lds, st, g, x, go, out, saved, gx);
 }
 
 // ---- fast-path launches (nfp_fast.h) ----------------------------------------------------------
@@ -471,12 +481,10 @@ int launch_fwd_fast_t(KP g, const void* x, void* out, float* saved, hipStream_t 
   if (POOL) red += (size_t)Win<R>::N * g.P * 4;  // pooled-map staging
   size_t lds = slab > red ? slab : red;
   if (lds > (size_t)kLdsMax) return kNotApplicable;  // tables + slab do not fit: the generic kernels serve it
-  if (int rc = set_lds(fwd_fast<R, M, BF, NHWC, POOL, MAXT>, lds)) return rc;
-  hipLaunchKernelGGL((fwd_fast<R, M, BF, NHWC, POOL, MAXT>), dim3(g.B), dim3(T), lds, st, g, x, out, saved, gap, nfpm);
-  g_launches++;
   snprintf(g_variant, sizeof(g_variant), "fwd_fast<R%d,%s,%s,%s%s>", R, M == NFP_COSINE ? "cos" : "l2",
            BF ? "bf16" : "f32", NHWC ? "nhwc" : "nchw", POOL ? ",pool" : "");
-  return hip_ok(hipGetLastError(), "launch fwd_fast");
+  return launch("fwd_fast", fwd_fast<R, M, BF, NHWC, POOL, MAXT>, dim3(g.B), dim3(T), lds, st, g, x, out, saved, gap,
+                nfpm);
 }
 
 template <int R, int M>
@@ -516,13 +524,10 @@ int launch_bwd_fast_t(KP g, const void* x, const void* go, const void* out, cons
   size_t xs = slab > tables ? slab : tables;
   size_t lds = ((wt + 15) & ~(size_t)15) + xs;
   if (lds > (size_t)kLdsMax) return kNotApplicable;  // tables + slab do not fit: the generic kernels serve it
-  if (int rc = set_lds(bwd_fast<R, M, BF, NHWC, POOL>, lds)) return rc;
-  hipLaunchKernelGGL((bwd_fast<R, M, BF, NHWC, POOL>), dim3(g.B, S), dim3(T), lds, st, g, x, go, out, saved, gx, ggap,
-                     gnfpm);
-  g_launches++;
   snprintf(g_variant, sizeof(g_variant), "bwd_fast<R%d,%s,%s,%s%s>", R, M == NFP_COSINE ? "cos" : "l2",
            BF ? "bf16" : "f32", NHWC ? "nhwc" : "nchw", POOL ? ",pool" : "");
-  return hip_ok(hipGetLastError(), "launch bwd_fast");
+  return launch("bwd_fast", bwd_fast<R, M, BF, NHWC, POOL>, dim3(g.B, S), dim3(T), lds, st, g, x, go, out, saved, gx,
+                ggap, gnfpm);
 }
 
 template <int R, int M>
@@ -608,10 +613,8 @@ int nfp_forward(const nfp_desc* d, const void* x, void* out, float* saved, void*
       gd.similarity = 1;  // raw dots first; the sign belongs to the softmax output (nfp.py:203-204)
       if (int rc = launch_fwd_generic<NFP_DOT>(gd, x, out, nullptr, st)) return rc;
       const long long n = (long long)g.B * g.O;
-      hipLaunchKernelGGL(attn_softmax_fwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, g, out);
-      g_launches++;
       strncat(g_variant, "+attn_softmax", sizeof(g_variant) - strlen(g_variant) - 1);
-      return hip_ok(hipGetLastError(), "launch attn_softmax_fwd");
+      return launch("attn_softmax_fwd", attn_softmax_fwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, g, out);
     }
     default:
       return fail(NFP_E_UNSUPPORTED, "measure %d (SharpenedCosine mixes batch elements in the reference, "
@@ -660,9 +663,9 @@ int nfp_backward(const nfp_desc* d, const void* x, const void* grad_out, const v
       if (g.dtype != NFP_F32) return fail(NFP_E_UNSUPPORTED, "attention: float32 only");
       float* gd = const_cast<float*>(saved);  // scratch handed over by nfp_forward's caller (nfp_saved_floats)
       const long long n = (long long)g.B * g.O;
-      hipLaunchKernelGGL(attn_softmax_bwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, g, grad_out, out, gd);
-      g_launches++;
-      if (int rc = hip_ok(hipGetLastError(), "launch attn_softmax_bwd")) return rc;
+      if (int rc = launch("attn_softmax_bwd", attn_softmax_bwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, g,
+                          grad_out, out, gd))
+        return rc;
       KP gdot = g;
       gdot.similarity = 1;
       gdot.godtype = NFP_F32;
@@ -671,6 +674,25 @@ int nfp_backward(const nfp_desc* d, const void* x, const void* grad_out, const v
     default:
       return fail(NFP_E_UNSUPPORTED, "measure %d (SharpenedCosine) has no HIP kernel", g.measure);
   }
+}
+
+// What would nfp_forward / nfp_backward launch for this descriptor?  Nothing touches the GPU: the dispatcher runs
+// in plan mode with 4 KiB-aligned stand-in pointers and the launches are described into `buf` as
+//   "<variant> | <kernel> grid=(x,y,z) block=t lds=bytes[; <kernel> ...]".
+int nfp_plan(const nfp_desc* d, int32_t backward, char* buf, int32_t buflen) {
+  if (!buf || buflen < 1) return fail(NFP_E_INVALID, "null plan buffer");
+  buf[0] = 0;
+  char keep[sizeof(g_variant)];
+  memcpy(keep, g_variant, sizeof(keep));
+  t_dry = true;
+  t_plan[0] = 0;
+  void* fake = (void*)(uintptr_t)0x1000;
+  const int rc = backward ? nfp_backward(d, fake, fake, fake, (const float*)fake, fake, nullptr)
+                          : nfp_forward(d, fake, fake, (float*)fake, nullptr);
+  t_dry = false;
+  if (rc == NFP_OK) snprintf(buf, (size_t)buflen, "%s | %s", g_variant, t_plan);
+  memcpy(g_variant, keep, sizeof(keep));
+  return rc;
 }
 
 // ---- fused nfp_pooling tail (models/NFP_Pooling.py:27-31) ----------------------------------------------

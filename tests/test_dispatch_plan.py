@@ -1,0 +1,117 @@
+"""Dispatch rules of libnfp_hip.so, checked WITHOUT a GPU through nfp_plan (include/nfp.h): which kernel serves
+which geometry, and that no descriptor the library accepts produces a launch outside the device's limits."""
+import ctypes
+import random
+import re
+
+import pytest
+
+from neighbour_feature_pooling_amd import _abi
+from neighbour_feature_pooling_amd.build import build_hip
+
+LDS_MAX = 160 * 1024
+
+
+@pytest.fixture(scope="module")
+def lib():
+    build_hip()
+    return _abi.load()
+
+
+def desc(shape, R=1, pad=None, stride=1, dil=1, mode="reflect", measure="cosine", p=2.0, dtype=_abi.F32,
+         channels_last=False):
+    B, C, H, W = shape
+    d = _abi.NfpDesc()
+    d.B, d.C, d.H, d.W = B, C, H, W
+    d.R, d.pad, d.stride, d.dilation = R, R if pad is None else pad, stride, dil
+    d.pad_mode = _abi.PAD_MODES.index(mode)
+    d.measure = _abi.measure_id(measure)
+    d.similarity, d.diff_weights, d.dtype = 1, int(measure in ("norm", "rmse")), dtype
+    d.p, d.eps, d.q_scs = p, 1e-6, 1e-6
+    if channels_last:
+        d.sxB, d.sxC, d.sxH, d.sxW = C * H * W, 1, W * C, C
+    else:
+        d.sxB, d.sxC, d.sxH, d.sxW = C * H * W, H * W, W, 1
+    return d
+
+
+def plan(lib, d, backward):
+    buf = ctypes.create_string_buffer(1024)
+    rc = lib.nfp_plan(ctypes.byref(d), int(backward), buf, len(buf))
+    return rc, buf.value.decode()
+
+
+def launches(text):
+    return [(m.group(1), tuple(int(v) for v in m.group(2).split(",")), int(m.group(3)), int(m.group(4)))
+            for m in re.finditer(r"(\w+) grid=\(([\d,]+)\) block=(\d+) lds=(\d+)", text)]
+
+
+def test_plan_does_not_launch_or_disturb_last_variant(lib):
+    before, n0 = lib.nfp_last_variant(), lib.nfp_launch_count()
+    rc, text = plan(lib, desc((64, 512, 7, 7)), False)
+    assert rc == 0 and text.startswith("fwd_fast<R1,cos,f32,nchw> | fwd_fast grid=(64,1,1)")
+    assert lib.nfp_launch_count() == n0 and lib.nfp_last_variant() == before
+
+
+@pytest.mark.parametrize("d_kw,fwd,bwd", [
+    (dict(shape=(64, 512, 7, 7)), "fwd_fast<R1,cos,f32,nchw>", "bwd_fast<R1,cos,f32,nchw>"),           # headline
+    (dict(shape=(256, 192, 14, 14), R=2, measure="norm", dtype=_abi.BF16), "fwd_fast<R2,l2,bf16,nchw>",
+     "bwd_fast<R2,l2,bf16,nchw>"),                                                                      # config 5
+    (dict(shape=(8, 512, 7, 7), channels_last=True), "fwd_fast<R1,cos,f32,nhwc>", "bwd_fast<R1,cos,f32,nhwc>"),
+    (dict(shape=(64, 512, 7, 7), measure="norm", p=1.0), "fwd_pairs", "bwd_gather"),                    # reference default p
+    (dict(shape=(64, 512, 7, 7), pad=0), "fwd_pairs", "bwd_gather"),                                    # pad != R
+    (dict(shape=(64, 512, 7, 7), stride=2), "fwd_pairs", "bwd_gather"),
+    (dict(shape=(64, 510, 7, 7)), "fwd_pairs", "bwd_gather"),                                           # C % 4 != 0
+    (dict(shape=(4, 64, 7, 7), mode="circular"), "fwd_pairs", "bwd_gather"),
+    (dict(shape=(4, 64, 7, 7), measure="jeffrey"), "fwd_pairs", "bwd_gather"),
+    (dict(shape=(4, 64, 7, 7), measure="attention"), "fwd_pairs+attn_softmax", "bwd_gather"),
+    (dict(shape=(64, 64, 56, 56)), "fwd_pairs", "bwd_gather_banded"),                                   # tables > LDS
+    (dict(shape=(2, 8, 100, 140)), "fwd_pairs", "bwd_gather_banded"),
+    (dict(shape=(2, 16, 64, 64), mode="circular"), "fwd_pairs", "bwd_generic"),                        # wraps: no bands
+])
+def test_which_kernel_serves_which_call(lib, d_kw, fwd, bwd):
+    d = desc(**d_kw)
+    rc, text = plan(lib, d, False)
+    assert rc == 0, lib.nfp_last_error()
+    assert text.split(" | ")[0] == fwd
+    rc, text = plan(lib, d, True)
+    assert rc == 0, lib.nfp_last_error()
+    assert text.split(" | ")[0] == bwd
+
+
+def test_small_batches_still_fill_the_chip(lib):
+    """At B = 64 the backward and the any-measure forward must put >= 256 workgroups on the 256 CUs."""
+    for d, backward in ((desc((64, 512, 7, 7)), True), (desc((64, 512, 7, 7), measure="dot"), False),
+                        (desc((64, 512, 7, 7), measure="dot"), True), (desc((16, 512, 7, 7)), True)):
+        _, text = plan(lib, d, backward)
+        name, grid, block, lds = launches(text)[0]
+        assert grid[0] * grid[1] * grid[2] >= 256, text
+
+
+def test_every_accepted_descriptor_launches_within_device_limits(lib):
+    """Randomised sweep over geometry / measure / dtype / layout: whatever the library accepts must describe
+    launches with LDS <= 160 KiB, <= 1024 threads and grid y/z <= 65535; what it refuses, it refuses with a message."""
+    rnd = random.Random(20260)
+    measures = [m for m in _abi.MEASURES if m != "scs"]
+    seen, accepted = set(), 0
+    for _ in range(3000):
+        H, W = rnd.choice([1, 2, 3, 5, 7, 9, 14, 16, 28, 33, 56, 64, 100, 150]), rnd.choice([1, 2, 4, 7, 8, 14, 28, 37, 56, 112, 200])
+        R, stride, dil = rnd.choice([1, 1, 1, 2, 2, 3, 5]), rnd.choice([1, 1, 1, 2, 3]), rnd.choice([1, 1, 1, 2, 3])
+        d = desc((rnd.choice([1, 3, 16, 64, 256, 1024]), rnd.choice([1, 3, 4, 16, 63, 192, 512, 960, 2048]), H, W), R=R,
+                 pad=rnd.choice([0, 1, R, R * dil, R * dil + 2]), stride=stride, dil=dil,
+                 mode=rnd.choice(_abi.PAD_MODES), measure=rnd.choice(measures), p=rnd.choice([1.0, 2.0, 3.0]),
+                 dtype=rnd.choice([_abi.F32, _abi.BF16]), channels_last=rnd.random() < 0.3)
+        for backward in (False, True):
+            rc, text = plan(lib, d, backward)
+            if rc != 0:
+                assert rc in (-1, -2) and lib.nfp_last_error()
+                continue
+            accepted += 1
+            ls = launches(text)
+            assert ls, text
+            for name, grid, block, lds in ls:
+                seen.add(name)
+                assert lds <= LDS_MAX and 1 <= block <= 1024, text
+                assert all(v >= 1 for v in grid) and grid[1] <= 65535 and grid[2] <= 65535, text
+    assert accepted > 2000
+    assert {"fwd_fast", "bwd_fast", "fwd_pairs", "bwd_gather", "bwd_gather_banded"} <= seen, seen
