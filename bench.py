@@ -181,17 +181,24 @@ def unfold_on_gpu(args, dev, steps=50):
                     "as PyTorch-ROCm ATen/MIOpen kernels on the same GPU and workload"}
 
 
-def pmc_traffic(kernel_prefix):
+def workload_key(args):
+    return f"{args.batch}x{args.channels}x{args.size}x{args.size} k{2 * args.radius + 1} {args.measure} {args.dtype}"
+
+
+def pmc_traffic(kernel_prefix, args):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes
     (profiles/traffic_latest.json, written by scripts/gpu_traffic.sh: FETCH_SIZE and WRITE_SIZE in
     separate rocprofv3 --pmc runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for
-    16-byte-per-lane streaming reads on gfx950).  None when no profile matches."""
+    16-byte-per-lane streaming reads on gfx950).  None when no profile of THIS workload is committed."""
     path = os.path.join(ROOT, "profiles", "traffic_latest.json")
     try:
         rec = json.load(open(path))
     except (OSError, ValueError):
         return None
-    for k, v in rec.get("kernels", {}).items():
+    kernels = rec.get("workloads", {}).get(workload_key(args))
+    if kernels is None and workload_key(args) == "64x512x7x7 k3 cosine f32":
+        kernels = rec.get("kernels", {})   # first-generation file: headline workload only
+    for k, v in (kernels or {}).items():
         if k.startswith(kernel_prefix):
             return v.get("hbm_bytes_per_launch")
     return None
@@ -311,7 +318,8 @@ def main():
             "roofline": {"bound": "hbm", "kernel": f"{dom}:{bwd_variant if dom == 'backward' else fwd_variant}",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": pmc_traffic("bwd_fast" if dom == "backward" else "fwd_fast"),
+                         "traffic": pmc_traffic((bwd_variant if dom == "backward" else fwd_variant)
+                                                .split("<")[0].split("+")[0], args),
                          "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_us": round(dom_t, 3)},
             "kernels": {"forward_us": round(t_fwd_saving, 3), "forward_nograd_us": round(t_fwd, 3),
                         "backward_us": round(t_bwd, 3), "forward_variant": fwd_variant,

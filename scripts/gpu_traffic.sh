@@ -36,3 +36,19 @@ for k, v in res.items():
 json.dump(out, open("gpurun_out/traffic.json", "w"), indent=1)
 print(json.dumps(out, indent=1))
 PY
+# merge into gpurun_out/traffic_workloads.json under this workload's key (bench.py::workload_key)
+python3 - "$@" <<'PY'
+import json, os, sys
+sys.path.insert(0, os.getcwd())
+import bench
+sys.argv = ["bench.py"] + sys.argv[1:]
+key = bench.workload_key(bench.parse())
+one = json.load(open("gpurun_out/traffic.json"))
+path = "profiles/traffic_latest.json"
+allw = json.load(open(path)) if os.path.exists(path) else {"note": one["note"]}
+allw.setdefault("workloads", {})[key] = one["kernels"]
+if "kernels" in allw and key == "64x512x7x7 k3 cosine f32":
+    allw["kernels"] = one["kernels"]
+json.dump(allw, open("gpurun_out/traffic_workloads.json", "w"), indent=1)
+print("merged", key, "->", "gpurun_out/traffic_workloads.json (copy to profiles/traffic_latest.json)")
+PY
