@@ -207,24 +207,31 @@ __global__ void __launch_bounds__(512) bwd_gather(const KP g, const GatherLds L,
   NFP_STAMP(2);
   __syncthreads();
   // compact the slots of each row / column into its reader list: readers through the CENTRE tap first (a
-  // pair of two of them makes this pixel the centre of an output), then the others, each in slot order
-  for (int i = t; i < g.H + g.W; i += T) {
+  // pair of two of them makes this pixel the centre of an output), then the others, each in slot order.
+  // One wavefront per list: lane = slot, position = running count + popcount of the ballot below the lane.
+  for (int i = t >> 6; i < g.H + g.W; i += T >> 6) {
     uint2* list = i < g.H ? yl + i * L.capY : xl + (i - g.H) * L.capX;
     const unsigned ctap = (unsigned)(i < g.H ? g.R * g.k : g.R);
-    unsigned cnt = 0;
-    for (int w = 0; w < nslot; ++w) {
-      const uint2 e = slots[i * nslot + w];
-      if (e.x != 0xFFFFFFFFu && (e.y >> 20) == ctap) list[cnt++] = e;
+    const int lane = t & 63;
+    unsigned cnt = 0, ncentre = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+      for (int w0 = 0; w0 < nslot; w0 += 64) {
+        const int w = w0 + lane;
+        uint2 e = make_uint2(0xFFFFFFFFu, 0u);
+        if (w < nslot) e = slots[i * nslot + w];
+        const bool pred = e.x != 0xFFFFFFFFu && (((e.y >> 20) == ctap) == (pass == 0));
+        const unsigned long long m = __ballot(pred);
+        if (pred) list[cnt + __popcll(m & ((1ull << lane) - 1ull))] = e;
+        cnt += (unsigned)__popcll(m);
+      }
+      if (pass == 0) ncentre = cnt;
     }
-    const unsigned ncentre = cnt;
-    for (int w = 0; w < nslot; ++w) {
-      const uint2 e = slots[i * nslot + w];
-      if (e.x != 0xFFFFFFFFu && (e.y >> 20) != ctap) list[cnt++] = e;
+    if (lane == 0) {
+      if (i < g.H)
+        yc[i] = cnt | (ncentre << 16);
+      else
+        xc[i - g.H] = cnt | (ncentre << 16);
     }
-    if (i < g.H)
-      yc[i] = cnt | (ncentre << 16);
-    else
-      xc[i - g.H] = cnt | (ncentre << 16);
   }
   NFP_STAMP(3);
 
@@ -600,11 +607,21 @@ __global__ void __launch_bounds__(512) fwd_pairs(const KP g, const PairsLds L, c
   NFP_STAMP(0);
 
   // ---- which input pixels does this tile of outputs read?  Only whole rows r0..r1 of x are staged. ------
-  if (t == 0) {
-    mm[0] = g.P;
-    mm[1] = -1;
+  // (When the launcher's bound is the whole image anyway, the window is the image: no search, one pass less.)
+#ifndef NFP_PAIRS_WHOLE
+#define NFP_PAIRS_WHOLE 1
+#endif
+#ifndef NFP_PAIRS_PARTS
+#define NFP_PAIRS_PARTS 8
+#endif
+  const bool whole = NFP_PAIRS_WHOLE && L.PSm == g.P + 1;
+  if (!whole) {
+    if (t == 0) {
+      mm[0] = g.P;
+      mm[1] = -1;
+    }
+    __syncthreads();
   }
-  __syncthreads();
   for (int i = t; i < L.Ot * g.k; i += T) {  // thread (output, kernel row) walks a row of taps
     const int ky = i / L.Ot, l = i - ky * L.Ot;
     const int oy = (o0 + l) / g.Wo, ox = (o0 + l) - oy * g.Wo, mid = (g.k * g.k) >> 1;
@@ -619,17 +636,23 @@ __global__ void __launch_bounds__(512) fwd_pairs(const KP g, const PairsLds L, c
         hi = max(hi, px);
       }
     }
-    if (hi >= 0) {
+    if (!whole && hi >= 0) {
       atomicMin(&mm[0], lo);
       atomicMax(&mm[1], hi);
     }
   }
-  __syncthreads();
-  const int r0 = mm[1] < 0 ? 0 : mm[0] / g.W, r1 = mm[1] < 0 ? -1 : mm[1] / g.W;
+  int r0 = 0, r1 = g.H - 1;
+  if (!whole) {
+    __syncthreads();
+    r0 = mm[1] < 0 ? 0 : mm[0] / g.W;
+    r1 = mm[1] < 0 ? -1 : mm[1] / g.W;
+  }
   const int p0 = r0 * g.W, np = (r1 - r0 + 1) * g.W, PS = np + 1;  // np + 1 <= L.PSm by the launcher's bound
-  for (int i = t; i < (g.N + 1) * L.Ot; i += T) {  // global pixel -> window pixel (np = the zero pixel)
-    const int px = tap[i];
-    tap[i] = (unsigned short)(px < g.P ? px - p0 : np);
+  if (!whole) {
+    for (int i = t; i < (g.N + 1) * L.Ot; i += T) {  // global pixel -> window pixel (np = the zero pixel)
+      const int px = tap[i];
+      tap[i] = (unsigned short)(px < g.P ? px - p0 : np);
+    }
   }
   for (int i = t; i < 2 * PS; i += T) st[i] = 0.f;
   for (int p = t; p < PS; p += T) {
@@ -706,24 +729,35 @@ __global__ void __launch_bounds__(512) fwd_pairs(const KP g, const PairsLds L, c
       for (int j = 0; j < NN; ++j) red[(cg * NN + j) * L.Ot + ol] = acc[j];
     }
     __syncthreads();
-    // thread (output ol, neighbour row cg + k*rows): one division per thread for the whole kernel (ol, cg above)
-    if (ol < on) {
-      const int rows = T / L.Ot;
-      for (int j = cg; j < NN && n0 + j < g.N; j += rows) {
-        const int n = n0 + j;
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;  // four interleaved partial sums, combined in a fixed order
-        int c2 = 0;
-        for (; c2 + 3 < L.G; c2 += 4) {
-          s0 += red[((c2 + 0) * NN + j) * L.Ot + ol];
-          s1 += red[((c2 + 1) * NN + j) * L.Ot + ol];
-          s2 += red[((c2 + 2) * NN + j) * L.Ot + ol];
-          s3 += red[((c2 + 3) * NN + j) * L.Ot + ol];
-        }
-        for (; c2 < L.G; ++c2) s0 += red[(c2 * NN + j) * L.Ot + ol];
-        const float s = (s0 + s1) + (s2 + s3);
+    // thread (output ol, row cg): one division per thread for the whole kernel (ol, cg above).  With many
+    // channel groups and spare rows of threads the sum over groups is split into `parts` interleaved partial
+    // sums first (written back over group rows 0..parts-1, which only their own thread reads).
+    const int rows = T / L.Ot, NNv = min(NN, g.N - n0);
+    const int parts = max(1, min(min(rows / NNv, NFP_PAIRS_PARTS), L.G));
+    if (parts > 1) {
+      float s = 0.f;
+      const int j = cg % NNv, part = cg / NNv;
+      const bool mine = ol < on && part < parts;
+      if (mine)
+        for (int c2 = part; c2 < L.G; c2 += parts) s += red[(c2 * NN + j) * L.Ot + ol];
+      if (mine) red[(part * NN + j) * L.Ot + ol] = s;
+      __syncthreads();
+      if (ol < on && cg < NNv) {
+        const int n = n0 + cg;
+        float v = 0.f;
+        for (int p2 = 0; p2 < parts; ++p2) v += red[(p2 * NN + cg) * L.Ot + ol];
         const int qz = tap[n * L.Ot + ol];
-        const float v = Meas<M>::fin(s, st[pcz], st[PS + pcz], st[qz], st[PS + qz], g);
-        stx(out, ((long long)b * g.N + n) * g.O + o0 + ol, v, g.dtype);
+        stx(out, ((long long)b * g.N + n) * g.O + o0 + ol,
+            Meas<M>::fin(v, st[pcz], st[PS + pcz], st[qz], st[PS + qz], g), g.dtype);
+      }
+    } else if (ol < on) {
+      for (int j = cg; j < NNv; j += rows) {
+        const int n = n0 + j;
+        float s = 0.f;
+        for (int c2 = 0; c2 < L.G; ++c2) s += red[(c2 * NN + j) * L.Ot + ol];
+        const int qz = tap[n * L.Ot + ol];
+        stx(out, ((long long)b * g.N + n) * g.O + o0 + ol,
+            Meas<M>::fin(s, st[pcz], st[PS + pcz], st[qz], st[PS + qz], g), g.dtype);
       }
     }
   }
