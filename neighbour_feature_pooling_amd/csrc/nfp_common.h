@@ -50,25 +50,19 @@ __device__ __forceinline__ void stx(void* x, long long i, float v, int dtype) {
     ((uint16_t*)x)[i] = f32_to_bf16(v);
 }
 
-// nn.Conv2d padding_mode index map (reflect: -i / 2(n-1)-i; replicate: clamp;
-// circular: wrap; zeros: -1 = the tap reads 0).
+// nn.Conv2d padding_mode index map (reflect: -i / 2(n-1)-i; replicate: clamp; circular: wrap; zeros: -1 =
+// the tap reads 0).  Branch-free: one select per mode.  make_kp guarantees pad < n (reflect) and pad <= n
+// (circular), so a single fold / wrap is exact.  (Branchy index code is slow out of proportion: it runs once
+// per kernel, from a cold instruction cache, and every taken branch is a fetch stall.)
 __device__ __forceinline__ int map_index(int t, int n, int mode) {
-  if (t >= 0 && t < n) return t;
-  if (mode == NFP_PAD_REFLECT) return t < 0 ? -t : 2 * (n - 1) - t;
-  if (mode == NFP_PAD_REPLICATE) return t < 0 ? 0 : n - 1;
-  if (mode == NFP_PAD_CIRCULAR) {
-    int r = t % n;
-    return r < 0 ? r + n : r;
-  }
-  return -1;
-}
-// branch-free form for zeros / reflect / replicate (the hot path never sees circular)
-__device__ __forceinline__ int map_index_bf(int t, int n, int mode) {
-  const int refl = t < 0 ? -t : (t >= n ? 2 * (n - 1) - t : t);
+  const bool lo = t < 0, hi = t >= n;
+  const int refl = lo ? -t : (hi ? 2 * (n - 1) - t : t);
   const int repl = min(max(t, 0), n - 1);
-  const int zero = (t >= 0 && t < n) ? t : -1;
-  return mode == NFP_PAD_REFLECT ? refl : (mode == NFP_PAD_REPLICATE ? repl : zero);
+  const int circ = lo ? t + n : (hi ? t - n : t);
+  const int zero = (lo || hi) ? -1 : t;
+  return mode == NFP_PAD_REFLECT ? refl : (mode == NFP_PAD_REPLICATE ? repl : (mode == NFP_PAD_CIRCULAR ? circ : zero));
 }
+__device__ __forceinline__ int map_index_bf(int t, int n, int mode) { return map_index(t, n, mode); }
 // flat input pixel of kernel tap (ky,kx) for output o; -1 = zero padding
 __device__ __forceinline__ int tap_pixel(const KP& g, int o, int ky, int kx) {
   int oy = o / g.Wo, ox = o - oy * g.Wo;
@@ -110,5 +104,12 @@ __device__ __forceinline__ float sgnf(float v) { return (float)((v > 0.f) - (v <
 __device__ __forceinline__ float frcp(float b) { return __builtin_amdgcn_rcpf(b); }
 __device__ __forceinline__ float fdiv(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
 __device__ __forceinline__ float fsqrt(float v) { return __builtin_amdgcn_sqrtf(v); }
+
+// floor(i / d) for 0 <= i, 1 <= d, i + d < 2^21: exact (the 1-ulp reciprocal and the product perturb (i + 0.5)/d
+// by less than 0.5/d), in 4 instructions instead of the ~30 of an integer division.  Index arithmetic of
+// once-per-kernel setup code is instruction-FETCH bound (cold I-cache), so code size there is time.
+__device__ __forceinline__ int fdivi(int i, int d) {
+  return (int)(((float)i + 0.5f) * __builtin_amdgcn_rcpf((float)d));
+}
 
 }  // namespace nfp

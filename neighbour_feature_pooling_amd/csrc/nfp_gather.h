@@ -35,8 +35,9 @@ struct GatherLds {
   int yl, xl;      // uint2 [H][capY] / [W][capX]  per-row / per-column reader lists (see axis_reader)
   int yc, xc;      // u32   [H] / [W]              their lengths | number of leading centre-tap readers << 16
   int capY, capX;
-  int xs;          // float4 slab [Cq][P + 1] (word offset, multiple of 4); pixel P of every quad is 0.
-                   // The uncompacted reader slots live here until the first slab is staged.
+  int sl;          // uint2 [(H + W)][(2*pad + 1)*k]  uncompacted reader slots
+  int Ts;          // threads (whole wavefronts) that stage the first slab while the others build the tables
+  int xs;          // float4 slab [Cq][P + 1] (word offset, multiple of 4); pixel P of every quad is 0
   int Cq;          // channel quads per slab
   int Qwg;         // channel quads per workgroup
 };
@@ -57,7 +58,7 @@ __device__ __forceinline__ uint2 axis_reader(const KP& g, int i, int n, int no, 
   if (ic > 0 && map_index(tc, n, g.mode) != i) return e;
   const int nn = tc + g.pad - d * g.dil;
   if (nn < 0) return e;
-  const int oa = g.stride == 1 ? nn : nn / g.stride;
+  const int oa = g.stride == 1 ? nn : fdivi(nn, g.stride);
   if (oa * g.stride != nn || oa >= no) return e;
   const int ca = map_index(oa * g.stride + g.R * g.dil - g.pad, n, g.mode);
   e.x = rows ? (unsigned)(d * g.k * g.O + oa * g.Wo) : (unsigned)(d * g.O + oa);
@@ -94,10 +95,55 @@ __device__ __forceinline__ float4 finish_quad(float4 v, int left, float pv) {
 }
 template <bool BF>
 __device__ __forceinline__ void stage_quads_t(float4* xs, const void* x, const KP& g, int b, int qc0, int cqn,
-                                              const float* piv, int p0, int np) {
-  const int t = threadIdx.x, T = blockDim.x, PS = np + 1;
+                                              const float* piv, int p0, int np, int t, int T) {
+  const int PS = np + 1;  // t of T threads take part (a kernel may keep a wavefront back for its index tables)
   if (np <= 0) {
     for (int cq = t; cq < cqn; cq += T) xs[cq] = make_float4(0.f, 0.f, 0.f, 0.f);
+    return;
+  }
+  if (!BF && g.sW == 1 && g.sC != 1 && g.sH == (long long)g.W && np >= 4) {
+    // Dense NCHW float32: 4 channels x 4 consecutive pixels per step = four 16-byte loads along the pixel axis
+    // (global_load_dwordx4 needs only 4-byte alignment), transposed in registers into four float4 slots.
+    // The last (partial) group of a row re-reads the final four pixels.  Two blocks in flight per thread.
+    typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+    const int npg = (np + 3) >> 2;
+    const int TF = min(npg, T), TS = fdivi(T, TF);
+    const int ts = fdivi(t, TF), tf = t - ts * TF;
+    const float* xf = (const float*)x + (long long)b * g.sB + p0;
+    if (ts < TS) {
+      for (int s0 = ts; s0 < cqn; s0 += 2 * TS) {
+        for (int f = tf; f < npg; f += TF) {
+          const int pb = min(4 * f, np - 4);  // first pixel of the block (the last block is shifted back)
+          f4u v[2][4];
+          int cqs[2], lefts[2];
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            cqs[u] = min(s0 + u * TS, cqn - 1);
+            const int c = 4 * (qc0 + cqs[u]);
+            lefts[u] = g.C - 1 - c;
+            const float* row = xf + (long long)c * g.sC + pb;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[u][i] = *(const f4u*)(row + min(i, lefts[u]) * g.sC);
+          }
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            if (s0 + u * TS < cqn) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                const float pv = piv ? piv[pb + j] : 0.f;
+                float4 w;
+                w.x = v[u][0][j] - pv;
+                w.y = lefts[u] >= 1 ? v[u][1][j] - pv : 0.f;
+                w.z = lefts[u] >= 2 ? v[u][2][j] - pv : 0.f;
+                w.w = lefts[u] >= 3 ? v[u][3][j] - pv : 0.f;
+                xs[cqs[u] * PS + pb + j] = w;
+              }
+            }
+          }
+        }
+      }
+    }
+    for (int cq = t; cq < cqn; cq += T) xs[cq * PS + np] = make_float4(0.f, 0.f, 0.f, 0.f);
     return;
   }
   // 2-D thread grid, fast axis = what is contiguous in memory: pixels (NCHW) or channel quads (channels-last);
@@ -105,8 +151,8 @@ __device__ __forceinline__ void stage_quads_t(float4* xs, const void* x, const K
   const bool nhwc = g.sC == 1;
   const bool dense = g.sH == (long long)g.W * g.sW;  // pixel p sits at p * sW: no row / column split needed
   const int nf = nhwc ? cqn : np, ns = nhwc ? np : cqn;
-  const int TF = min(nf, T), TS = T / TF;
-  const int tf = t % TF, ts = t / TF;
+  const int TF = min(nf, T), TS = fdivi(T, TF);
+  const int ts = fdivi(t, TF), tf = t - ts * TF;
   const long long img = (long long)b * g.sB;
   constexpr int U = 8;  // quads in flight per thread: staging is latency-bound, not issue-bound
   if (ts < TS) {
@@ -123,7 +169,7 @@ __device__ __forceinline__ void stage_quads_t(float4* xs, const void* x, const K
           if (dense) {
             off = (long long)(p0 + ps[u]) * g.sW;
           } else {
-            const int pg = p0 + ps[u], y = pg / g.W;
+            const int pg = p0 + ps[u], y = fdivi(pg, g.W);
             off = (long long)y * g.sH + (long long)(pg - y * g.W) * g.sW;
           }
           const int c = 4 * (qc0 + cqs[u]);
@@ -141,11 +187,11 @@ __device__ __forceinline__ void stage_quads_t(float4* xs, const void* x, const K
   for (int cq = t; cq < cqn; cq += T) xs[cq * PS + np] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 __device__ __forceinline__ void stage_quads(float4* xs, const void* x, const KP& g, int b, int qc0, int cqn,
-                                            const float* piv, int p0, int np) {
+                                            const float* piv, int p0, int np, int t, int T) {
   if (g.dtype == NFP_F32)
-    stage_quads_t<false>(xs, x, g, b, qc0, cqn, piv, p0, np);
+    stage_quads_t<false>(xs, x, g, b, qc0, cqn, piv, p0, np, t, T);
   else
-    stage_quads_t<true>(xs, x, g, b, qc0, cqn, piv, p0, np);
+    stage_quads_t<true>(xs, x, g, b, qc0, cqn, piv, p0, np, t, T);
 }
 
 template <int M>
@@ -179,30 +225,39 @@ __global__ void __launch_bounds__(512) bwd_gather(const KP g, const GatherLds L,
   NFP_STAMP_INIT();
   NFP_STAMP(0);
 
-  // ---- tables: reader slots of every row and column (geometry only), one slot per thread ---------------
+  // The first L.Ts threads stage the first slab; the others build the tables meanwhile.  Each part is one or two
+  // passes of dependent work (index arithmetic; global load -> arithmetic -> LDS), i.e. latency, not throughput:
+  // side by side they cost the longer of the two instead of the sum.
+  const int Q = (g.C + 3) >> 2;
+  const int q_begin = blockIdx.y * L.Qwg, q_end = min(Q, q_begin + L.Qwg);
   const int nslot = (2 * g.pad + 1) * g.k;
-  uint2* slots = (uint2*)xs;
-  for (int s = t; s < (g.H + g.W) * nslot; s += T) {
-    const int i = s / nslot, w = s - i * nslot, ic = w / g.k, d = w - ic * g.k;
-    slots[s] = i < g.H ? axis_reader(g, i, g.H, g.Ho, ic, d, true) : axis_reader(g, i - g.H, g.W, g.Wo, ic, d, false);
-  }
-  NFP_STAMP(1);
-  // ---- tables: per-pair coefficients and neighbour pixels (this image) ----------------------------------
-  for (int j = t; j < ON; j += T) {
-    const int n = j / g.O, o = j - n * g.O;
-    const int q = nbr_pixel(g, o, n), pc = tap_pixel(g, o, g.R, g.R);
-    const long long oi = ((long long)b * g.N + n) * g.O + o;
-    const float sp0 = (Meas<M>::NSTAT > 0 && pc >= 0) ? sv[pc] : 0.f;
-    const float sp1 = (Meas<M>::NSTAT > 1 && pc >= 0) ? sv[g.P + pc] : 0.f;
-    const float sq0 = (Meas<M>::NSTAT > 0 && q >= 0) ? sv[q] : 0.f;
-    const float sq1 = (Meas<M>::NSTAT > 1 && q >= 0) ? sv[g.P + q] : 0.f;
-    const Coef c = Meas<M>::coef(ldx(go, oi, g.godtype), ldx(out, oi, g.dtype), sp0, sp1, sq0, sq1, g);
-    cf[j] = c.k0;
-    if (NC > 1) cf[ON + j] = c.k1;
-    if (NC > 2) cf[2 * ON + j] = c.k2;
-    if (NC > 3) cf[3 * ON + j] = c.k3;
-    if (NC > 4) cf[4 * ON + j] = c.k4;
-    nbq[j] = (unsigned short)(q < 0 ? g.P : q);
+  uint2* slots = (uint2*)(lds + L.sl);
+  if (t < L.Ts) {
+    stage_quads(xs, x, g, b, q_begin, min(L.Cq, q_end - q_begin), nullptr, 0, g.P, t, L.Ts);
+  } else {
+    const int tt = t - L.Ts, TT = T - L.Ts;
+    // ---- tables: reader slots of every row and column (geometry only), one slot per thread ---------------
+    for (int s = tt; s < (g.H + g.W) * nslot; s += TT) {
+      const int i = fdivi(s, nslot), w = s - i * nslot, ic = fdivi(w, g.k), d = w - ic * g.k;
+      slots[s] = i < g.H ? axis_reader(g, i, g.H, g.Ho, ic, d, true) : axis_reader(g, i - g.H, g.W, g.Wo, ic, d, false);
+    }
+    // ---- tables: per-pair coefficients and neighbour pixels (this image) ----------------------------------
+    for (int j = tt; j < ON; j += TT) {
+      const int n = fdivi(j, g.O), o = j - n * g.O;
+      const int q = nbr_pixel(g, o, n), pc = tap_pixel(g, o, g.R, g.R);
+      const long long oi = ((long long)b * g.N + n) * g.O + o;
+      const float sp0 = (Meas<M>::NSTAT > 0 && pc >= 0) ? sv[pc] : 0.f;
+      const float sp1 = (Meas<M>::NSTAT > 1 && pc >= 0) ? sv[g.P + pc] : 0.f;
+      const float sq0 = (Meas<M>::NSTAT > 0 && q >= 0) ? sv[q] : 0.f;
+      const float sq1 = (Meas<M>::NSTAT > 1 && q >= 0) ? sv[g.P + q] : 0.f;
+      const Coef c = Meas<M>::coef(ldx(go, oi, g.godtype), ldx(out, oi, g.dtype), sp0, sp1, sq0, sq1, g);
+      cf[j] = c.k0;
+      if (NC > 1) cf[ON + j] = c.k1;
+      if (NC > 2) cf[2 * ON + j] = c.k2;
+      if (NC > 3) cf[3 * ON + j] = c.k3;
+      if (NC > 4) cf[4 * ON + j] = c.k4;
+      nbq[j] = (unsigned short)(q < 0 ? g.P : q);
+    }
   }
   NFP_STAMP(2);
   __syncthreads();
@@ -236,21 +291,21 @@ __global__ void __launch_bounds__(512) bwd_gather(const KP g, const GatherLds L,
   NFP_STAMP(3);
 
   // ---- channel loop ------------------------------------------------------------------------------------
-  const int Q = (g.C + 3) >> 2;
-  const int q_begin = blockIdx.y * L.Qwg, q_end = min(Q, q_begin + L.Qwg);
   const unsigned mid = (unsigned)((g.k * g.k) >> 1);
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int qc0 = q_begin; qc0 < q_end; qc0 += L.Cq) {
     const int cqn = min(L.Cq, q_end - qc0);
-    __syncthreads();  // tables complete, slots consumed / previous slab consumed
+    __syncthreads();  // tables and first slab complete / previous slab consumed
     if (qc0 == q_begin) NFP_STAMP(4);
-    stage_quads(xs, x, g, b, qc0, cqn, nullptr, 0, g.P);
-    __syncthreads();
+    if (qc0 != q_begin) {
+      stage_quads(xs, x, g, b, qc0, cqn, nullptr, 0, g.P, t, T);
+      __syncthreads();
+    }
     if (qc0 == q_begin) NFP_STAMP(5);
     const int nqb = (cqn + QB - 1) / QB;
     for (int i = t; i < nqb * g.P; i += T) {
-      const int qb = i / g.P, r = i - qb * g.P;
-      const int ry = r / g.W, rx = r - ry * g.W;
+      const int qb = fdivi(i, g.P), r = i - qb * g.P;
+      const int ry = fdivi(r, g.W), rx = r - ry * g.W;
       const float4* slab[QB];
       float4 a[QB], acc[QB];
 #pragma unroll
@@ -348,7 +403,7 @@ __device__ __forceinline__ uint2 axis_reader_raw(const KP& g, int i, int n, int 
   if (ic > 0 && map_index(tc, n, g.mode) != i) return e;
   const int nn = tc + g.pad - d * g.dil;
   if (nn < 0) return e;
-  const int oa = g.stride == 1 ? nn : nn / g.stride;
+  const int oa = g.stride == 1 ? nn : fdivi(nn, g.stride);
   if (oa * g.stride != nn || oa >= no) return e;
   e.x = (unsigned)d | ((unsigned)oa << 8);
   e.y = (unsigned)map_index(oa * g.stride + g.R * g.dil - g.pad, n, g.mode);
@@ -384,7 +439,7 @@ __global__ void __launch_bounds__(512) bwd_gather_banded(const KP g, const BandL
   const int nslot = (2 * g.pad + 1) * g.k;
   uint2* slots = (uint2*)xs;
   for (int s = t; s < (nr + g.W) * nslot; s += T) {
-    const int i = s / nslot, w = s - i * nslot, ic = w / g.k, d = w - ic * g.k;
+    const int i = fdivi(s, nslot), w = s - i * nslot, ic = fdivi(w, g.k), d = w - ic * g.k;
     uint2 e;
     if (i < nr) {
       e = axis_reader_raw(g, ra + i, g.H, g.Ho, ic, d);
@@ -408,13 +463,13 @@ __global__ void __launch_bounds__(512) bwd_gather_banded(const KP g, const BandL
   const int o_base = oya * g.Wo;
   // ---- which rows of x do the outputs centred in the band pair it with? -----------------------------------
   for (int j = t; j < ON; j += T) {
-    const int n = j / Ol, o = o_base + (j - n * Ol);
+    const int n = fdivi(j, Ol), o = o_base + (j - n * Ol);
     const int pc = tap_pixel(g, o, g.R, g.R);
     if (pc >= ra * g.W && pc < rb * g.W) {
       const int q = nbr_pixel(g, o, n);
       if (q >= 0) {
-        atomicMin(&mm[2], q / g.W);
-        atomicMax(&mm[3], q / g.W);
+        atomicMin(&mm[2], fdivi(q, g.W));
+        atomicMax(&mm[3], fdivi(q, g.W));
       }
     }
   }
@@ -463,7 +518,7 @@ __global__ void __launch_bounds__(512) bwd_gather_banded(const KP g, const BandL
       xc[i - nr] = cnt | (ncentre << 16);
   }
   for (int j = t; j < ON; j += T) {
-    const int n = j / Ol, o = o_base + (j - n * Ol);
+    const int n = fdivi(j, Ol), o = o_base + (j - n * Ol);
     const int q = nbr_pixel(g, o, n), pc = tap_pixel(g, o, g.R, g.R);
     const long long oi = ((long long)b * g.N + n) * g.O + o;
     const float sp0 = (Meas<M>::NSTAT > 0 && pc >= 0) ? sv[pc] : 0.f;
@@ -491,12 +546,12 @@ __global__ void __launch_bounds__(512) bwd_gather_banded(const KP g, const BandL
   for (int qc0 = q_begin; qc0 < q_end; qc0 += L.Cq) {
     const int cqn = min(L.Cq, q_end - qc0);
     __syncthreads();  // tables complete, slots consumed / previous slab consumed
-    stage_quads(xs, x, g, b, qc0, cqn, nullptr, p0, np);
+    stage_quads(xs, x, g, b, qc0, cqn, nullptr, p0, np, t, T);
     __syncthreads();
     const int nqb = (cqn + QB - 1) / QB;
     for (int i = t; i < nqb * nbp; i += T) {
-      const int qb = i / nbp, rl = i - qb * nbp;
-      const int ryl = rl / g.W, rx = rl - ryl * g.W, ry = ra + ryl;
+      const int qb = fdivi(i, nbp), rl = i - qb * nbp;
+      const int ryl = fdivi(rl, g.W), rx = rl - ryl * g.W, ry = ra + ryl;
       const int r = (ry - w0) * g.W + rx;  // window pixel of this band pixel
       const float4* slab[QB];
       float4 a[QB], acc[QB];
@@ -584,6 +639,7 @@ struct PairsLds {
   int Ot;    // outputs per workgroup tile
   int G;     // channel groups in the pair loop (G * Ot <= blockDim)
   int Gs;    // channel groups in the per-pixel stat loop
+  int Tt;    // threads (whole wavefronts) that build the index tables while the others stage the first slab
 };
 
 template <int M, int NN>
@@ -596,74 +652,61 @@ __global__ void __launch_bounds__(512) fwd_pairs(const KP g, const PairsLds L, c
   float* piv = lds + L.piv;
   unsigned short* tap = (unsigned short*)(lds + L.tap);
   float* red = lds + L.red;
-  int* mm = (int*)(lds + L.mm);
   const int b = blockIdx.x, t = threadIdx.x, T = blockDim.x;
   const int Q = (g.C + 3) >> 2;
   const int o0 = blockIdx.y * L.Ot, on = min(L.Ot, g.O - o0);
-  const int ol = t % L.Ot, cg = t / L.Ot;
+  const int cg = fdivi(t, L.Ot), ol = t - cg * L.Ot;
   const bool active = cg < L.G && ol < on;
-  const int nchunk = (Q + L.Cq - 1) / L.Cq;
+  const int nchunk = fdivi(Q + L.Cq - 1, L.Cq);
   NFP_STAMP_INIT();
   NFP_STAMP(0);
 
-  // ---- which input pixels does this tile of outputs read?  Only whole rows r0..r1 of x are staged. ------
-  // (When the launcher's bound is the whole image anyway, the window is the image: no search, one pass less.)
-#ifndef NFP_PAIRS_WHOLE
-#define NFP_PAIRS_WHOLE 1
-#endif
-#ifndef NFP_PAIRS_PARTS
-#define NFP_PAIRS_PARTS 8
-#endif
-  const bool whole = NFP_PAIRS_WHOLE && L.PSm == g.P + 1;
-  if (!whole) {
-    if (t == 0) {
-      mm[0] = g.P;
-      mm[1] = -1;
-    }
-    __syncthreads();
-  }
-  for (int i = t; i < L.Ot * g.k; i += T) {  // thread (output, kernel row) walks a row of taps
-    const int ky = i / L.Ot, l = i - ky * L.Ot;
-    const int oy = (o0 + l) / g.Wo, ox = (o0 + l) - oy * g.Wo, mid = (g.k * g.k) >> 1;
-    const int yy = map_index(oy * g.stride + ky * g.dil - g.pad, g.H, g.mode);
-    int lo = g.P, hi = -1;
-    for (int kx = 0, tp = ky * g.k; kx < g.k; ++kx, ++tp) {
-      const int xx = map_index(ox * g.stride + kx * g.dil - g.pad, g.W, g.mode);
-      const int px = (l < on && yy >= 0 && xx >= 0) ? yy * g.W + xx : g.P;
-      tap[(tp == mid ? g.N : (tp < mid ? tp : tp - 1)) * L.Ot + l] = (unsigned short)px;
-      if (px < g.P) {
-        lo = min(lo, px);
-        hi = max(hi, px);
-      }
-    }
-    if (!whole && hi >= 0) {
-      atomicMin(&mm[0], lo);
-      atomicMax(&mm[1], hi);
-    }
-  }
+  // ---- which rows of x does this tile of outputs read?  Only those are staged.  Its output rows oyA..oyB read
+  // padded rows oyA*s - pad .. oyB*s + 2*R*dil - pad, and what padding folds back lies inside the clamped
+  // window (the launcher bounds PSm with the same formula, or with the whole image for circular / over-padding).
+  const bool whole = L.PSm == g.P + 1;
   int r0 = 0, r1 = g.H - 1;
   if (!whole) {
+    const int oyA = fdivi(o0, g.Wo), oyB = fdivi(o0 + on - 1, g.Wo);
+    r0 = max(0, oyA * g.stride - g.pad);
+    r1 = min(g.H - 1, oyB * g.stride + 2 * g.R * g.dil - g.pad);
+  }
+  const int p0 = r0 * g.W, np = (r1 - r0 + 1) * g.W, PS = np + 1;
+  if (Pivot<M>::v) {  // the slab holds x - pivot: the pivots come first
+    for (int p = t; p < PS; p += T) {
+      float v = 0.f;
+      if (p < np) {
+        const int pg = p0 + p, y = fdivi(pg, g.W), xx = pg - y * g.W;
+        v = ldx(x, (long long)b * g.sB + (long long)y * g.sH + (long long)xx * g.sW, g.dtype);
+      }
+      piv[p] = v;
+    }
     __syncthreads();
-    r0 = mm[1] < 0 ? 0 : mm[0] / g.W;
-    r1 = mm[1] < 0 ? -1 : mm[1] / g.W;
   }
-  const int p0 = r0 * g.W, np = (r1 - r0 + 1) * g.W, PS = np + 1;  // np + 1 <= L.PSm by the launcher's bound
-  if (!whole) {
-    for (int i = t; i < (g.N + 1) * L.Ot; i += T) {  // global pixel -> window pixel (np = the zero pixel)
-      const int px = tap[i];
-      tap[i] = (unsigned short)(px < g.P ? px - p0 : np);
+  // The last wavefront builds the index tables (a few hundred dependent integer instructions: microseconds
+  // for one wavefront, nothing for the chip) while the others stage the first slab.
+  const int tw = T - L.Tt;
+  if (t >= tw) {
+    const int lane = t - tw;
+    for (int i = lane; i < L.Ot * g.k; i += L.Tt) {  // thread (output, kernel row) walks a row of taps
+      const int ky = fdivi(i, L.Ot), l = i - ky * L.Ot;
+      const int oy = fdivi(o0 + l, g.Wo), ox = (o0 + l) - oy * g.Wo, mid = (g.k * g.k) >> 1;
+      const int yy = map_index(oy * g.stride + ky * g.dil - g.pad, g.H, g.mode);
+      for (int kx = 0, tp = ky * g.k; kx < g.k; ++kx, ++tp) {
+        const int xx = map_index(ox * g.stride + kx * g.dil - g.pad, g.W, g.mode);
+        const int px = (l < on && yy >= 0 && xx >= 0) ? yy * g.W + xx - p0 : np;  // window pixel; np = the zero
+        tap[(tp == mid ? g.N : (tp < mid ? tp : tp - 1)) * L.Ot + l] = (unsigned short)px;
+      }
     }
+    for (int i = lane; i < 2 * PS; i += L.Tt) st[i] = 0.f;
+    if (!Pivot<M>::v)
+      for (int p = lane; p < PS; p += L.Tt) piv[p] = 0.f;
+  } else {
+    stage_quads(xs, x, g, b, 0, min(L.Cq, Q), Pivot<M>::v ? piv : nullptr, p0, np, t, tw);
   }
-  for (int i = t; i < 2 * PS; i += T) st[i] = 0.f;
-  for (int p = t; p < PS; p += T) {
-    float v = 0.f;
-    if (Pivot<M>::v && p < np) {
-      const int pg = p0 + p, y = pg / g.W, xx = pg - y * g.W;
-      v = ldx(x, (long long)b * g.sB + (long long)y * g.sH + (long long)xx * g.sW, g.dtype);
-    }
-    piv[p] = v;
-  }
+  NFP_STAMP(1);
   __syncthreads();
+  NFP_STAMP(2);
   const int pcz = tap[g.N * L.Ot + ol];
 
   for (int n0 = 0; n0 < g.N; n0 += NN) {
@@ -677,15 +720,15 @@ __global__ void __launch_bounds__(512) fwd_pairs(const KP g, const PairsLds L, c
     for (int ch = 0; ch < nchunk; ++ch) {
       const int qc0 = ch * L.Cq, cqn = min(L.Cq, Q - qc0);
       if (n0 == 0 || nchunk > 1) {
-        __syncthreads();  // previous slab consumed
-        if (ch == 0 && n0 == 0) NFP_STAMP(1);
-        stage_quads(xs, x, g, b, qc0, cqn, Pivot<M>::v ? piv : nullptr, p0, np);
-        __syncthreads();
-        if (ch == 0 && n0 == 0) NFP_STAMP(2);
+        if (!(n0 == 0 && ch == 0)) {  // (the prologue staged slab 0)
+          __syncthreads();            // previous slab consumed
+          stage_quads(xs, x, g, b, qc0, cqn, Pivot<M>::v ? piv : nullptr, p0, np, t, T);
+          __syncthreads();
+        }
         if (NS > 0 && n0 == 0) {
           // per-pixel stat sums of this chunk: thread (pixel, group) -> scratch -> st
           for (int i = t; i < L.Gs * np; i += T) {
-            const int gs = i / np, p = i - gs * np;
+            const int gs = fdivi(i, np), p = i - gs * np;
             float s0 = 0.f, s1 = 0.f;
             for (int cq = gs; cq < cqn; cq += L.Gs) {
               const float4 a = xs[cq * PS + p];  // padding channels are 0 and stat(0) adds nothing
@@ -699,7 +742,7 @@ __global__ void __launch_bounds__(512) fwd_pairs(const KP g, const PairsLds L, c
           }
           __syncthreads();
           for (int i = t; i < 2 * np; i += T) {
-            const int k = i / np, p = i - k * np;
+            const int k = fdivi(i, np), p = i - k * np;
             float s = st[k * PS + p];
             for (int gs = 0; gs < L.Gs; ++gs) s += red[(gs * 2 + k) * np + p];
             st[k * PS + p] = s;
@@ -732,11 +775,11 @@ __global__ void __launch_bounds__(512) fwd_pairs(const KP g, const PairsLds L, c
     // thread (output ol, row cg): one division per thread for the whole kernel (ol, cg above).  With many
     // channel groups and spare rows of threads the sum over groups is split into `parts` interleaved partial
     // sums first (written back over group rows 0..parts-1, which only their own thread reads).
-    const int rows = T / L.Ot, NNv = min(NN, g.N - n0);
-    const int parts = max(1, min(min(rows / NNv, NFP_PAIRS_PARTS), L.G));
+    const int rows = fdivi(T, L.Ot), NNv = min(NN, g.N - n0);
+    const int parts = max(1, min(min(fdivi(rows, NNv), 8), L.G));
     if (parts > 1) {
       float s = 0.f;
-      const int j = cg % NNv, part = cg / NNv;
+      const int part = fdivi(cg, NNv), j = cg - part * NNv;
       const bool mine = ol < on && part < parts;
       if (mine)
         for (int c2 = part; c2 < L.G; c2 += parts) s += red[(c2 * NN + j) * L.Ot + ol];

@@ -196,6 +196,18 @@ int launch_fwd_pairs_t(const KP& g, const void* x, void* out, float* saved, hipS
     Cq = (Q + nch - 1) / nch;
   }
   L.Cq = (int)Cq;
+  // wavefronts for the index tables vs the first slab: balance ~350*k clk per pass of 64 (output, kernel row)
+  // items against ~2.5 B/clk of staging per wavefront (measured on MI355X, scripts/diag_stamps.py)
+  double best = 1e30;
+  L.Tt = 64;
+  for (int nt = 1; nt <= 4; ++nt) {
+    const double tt = (double)((L.Ot * g.k + 64 * nt - 1) / (64 * nt)) * 350.0 * g.k;
+    const double ts = (double)Cq * (double)quad_bytes / ((T / 64 - nt) * 2.5);
+    if (std::max(tt, ts) < best) {
+      best = std::max(tt, ts);
+      L.Tt = 64 * nt;
+    }
+  }
   const size_t lds = (size_t)w * 4 + (size_t)Cq * quad_bytes;
   snprintf(g_variant, sizeof(g_variant), "fwd_pairs");
   return launch("fwd_pairs", fwd_pairs<M, NN>, dim3(g.B, tiles), dim3(T), lds, st, g, L, x, out, saved);
@@ -258,7 +270,7 @@ int launch_bwd_gather(const KP& g, const void* x, const void* go, const void* ou
   const long long ON = (long long)g.O * g.N;
   // index ranges the packed tables hold (nfp_gather.h)
   if (force_atomic() || force_bands() > 0 || ON > 65535 || g.P > 65534 || g.k > 15 || g.pad > 8 || g.H >= 16383 ||
-      g.W >= 16383)
+      g.W >= 16383 || (long long)(g.H + g.W) * (2 * g.pad + 1) * g.k >= (1 << 20))
     return kNotApplicable;
   auto folds = [&](int n) {  // padded coordinates that can fold onto one coordinate of an axis of size n
     if (g.pad == 0 || g.mode == NFP_PAD_ZEROS) return 1;
@@ -277,13 +289,14 @@ int launch_bwd_gather(const KP& g, const void* x, const void* go, const void* ou
   L.xl = (int)w;  w += 2LL * g.W * L.capX;
   L.yc = (int)w;  w += g.H;
   L.xc = (int)w;  w += g.W;
+  w = (w + 1) & ~1LL;
+  L.sl = (int)w;  w += 2LL * (g.H + g.W) * (2 * g.pad + 1) * g.k;
   w = (w + 3) & ~3LL;
   if (w * 4 > kLdsMax) return kNotApplicable;
   L.xs = (int)w;
+  L.Ts = 128;  // of 512 threads
   const size_t table_bytes = (size_t)w * 4, quad_bytes = (size_t)(g.P + 1) * 16;
-  const size_t slot_bytes = (size_t)(g.H + g.W) * (2 * g.pad + 1) * g.k * 8;  // scratch that precedes the first slab
-  if (table_bytes + QB * quad_bytes > (size_t)kLdsMax || table_bytes + slot_bytes > (size_t)kLdsMax)
-    return kNotApplicable;
+  if (table_bytes + QB * quad_bytes > (size_t)kLdsMax) return kNotApplicable;
   const int Q = (g.C + 3) / 4;
   // channel split: enough workgroups to fill the chip at small batch, whole QB blocks per workgroup
   int S = (NFP_GATHER_WGS + g.B - 1) / g.B;
@@ -299,7 +312,7 @@ int launch_bwd_gather(const KP& g, const void* x, const void* go, const void* ou
   int Cq = (int)(budget / quad_bytes) / QB * QB;
   if (Cq > L.Qwg) Cq = L.Qwg;
   L.Cq = Cq;
-  const size_t lds = table_bytes + std::max((size_t)Cq * quad_bytes, slot_bytes);
+  const size_t lds = table_bytes + (size_t)Cq * quad_bytes;
   snprintf(g_variant, sizeof(g_variant), "bwd_gather");
   return launch("bwd_gather", bwd_gather<M, QB>, dim3(g.B, S), dim3(512), lds, st, g, L, x, go, out, saved, gx);
 }
@@ -309,7 +322,9 @@ template <int M>
 int launch_bwd_gather_banded(const KP& g, const void* x, const void* go, const void* out, const float* saved,
                              void* gx, hipStream_t st) {
   constexpr int QB = NFP_GATHER_QB, NC = NCoef<M>::v;
-  if (force_atomic() || g.k > 15 || g.pad > 8 || g.H >= 16383 || g.W >= 16383) return kNotApplicable;
+  if (force_atomic() || g.k > 15 || g.pad > 8 || g.H >= 16383 || g.W >= 16383 ||
+      (long long)(g.H + g.W) * (2 * g.pad + 1) * g.k >= (1 << 20))
+    return kNotApplicable;
   auto folds = [&](int n) {
     if (g.pad == 0 || g.mode == NFP_PAD_ZEROS) return 1;
     if (g.mode == NFP_PAD_REPLICATE) return n == 1 ? 2 * g.pad + 1 : g.pad + 1;

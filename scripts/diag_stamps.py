@@ -45,8 +45,10 @@ def report(name, nwg, nst):
     print(f"{name}: {nwg} workgroups; WG start spread {start.max():.0f} ns; last WG ends at {end.max():.0f} ns; "
           f"per-WG body median {np.median(tot_ns):.0f} ns = {np.median(tot_clk):.0f} clk "
           f"(~{np.median(tot_clk) / max(np.median(tot_ns), 1) :.2f} GHz)")
-    if name.startswith("fwd"):
-        print(f"   stamp overhead (0->6): median {np.median(clk_all[:,6]-clk_all[:,0]):.0f} clk; 6->1: {np.median(clk_all[:,1]-clk_all[:,6]):.0f} clk")
+    full = buf.cpu().numpy().reshape(-1, 16, 2)[:nwg, :, 0].astype(np.float64)
+    extra = [i for i in range(nst, 16) if np.median(full[:, i]) > 0]
+    if extra:
+        print("   extra stamps (clk after stamp 0): " + ", ".join(f"{i}: {np.median(full[:, i] - full[:, 0]):.0f}" for i in extra))
     for i in range(nst - 1):
         print(f"   phase {i}->{i + 1}: median {np.median(dclk[:, i]):8.0f} clk  {np.median(dwall[:, i]):7.0f} ns   "
               f"max {dclk[:, i].max():8.0f} clk")
