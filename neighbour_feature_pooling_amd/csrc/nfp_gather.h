@@ -206,6 +206,94 @@ __device__ __forceinline__ Coef load_coef(const float* cf, int ON, int j) {
   return c;
 }
 
+// grad_x of one (pixel, QB channel quads) item: centre role + neighbour role over the pixel's reader lists.
+// Two pairs are in flight per step (index -> coefficient / slab reads -> arithmetic is a chain of LDS latencies;
+// N = k*k - 1 is a multiple of 8, so the centre loop needs no remainder).
+template <int M, int QB>
+__device__ __forceinline__ void gather_item(const KP& g, const float4* const (&slab)[QB], const float4 (&a)[QB],
+                                            float4 (&acc)[QB], const uint2* yrow, const uint2* xrow, unsigned ycw,
+                                            unsigned xcw, const float* cf, int ON, const unsigned short* nbq, int Os,
+                                            unsigned zpix, unsigned mid) {
+  const unsigned ny = ycw & 0xFFFFu, nx = xcw & 0xFFFFu, nyc = ycw >> 16, nxc = xcw >> 16;
+  // centre role: r is the centre of output o (exactly one for the usual geometries, none or several when
+  // stride > 1 or the padding exceeds the kernel radius)
+  for (unsigned iy = 0; iy < nyc; ++iy) {
+    const uint2 ey = yrow[iy];
+    for (unsigned ix = 0; ix < nxc; ++ix) {
+      const uint2 ex = xrow[ix];
+      for (int n = 0, j = (int)(ey.x + ex.x) - (int)mid * Os; n < g.N; n += 2, j += 2 * Os) {
+        const unsigned q0 = nbq[j], q1 = nbq[j + Os];
+        const Coef c0 = load_coef<M>(cf, ON, j), c1 = load_coef<M>(cf, ON, j + Os);
+        float4 b0[QB], b1[QB];
+#pragma unroll
+        for (int u = 0; u < QB; ++u) {
+          b0[u] = slab[u][q0];
+          b1[u] = slab[u][q1];
+        }
+#pragma unroll
+        for (int u = 0; u < QB; ++u) {
+          float da, db;
+          Meas<M>::grad(a[u].x, b0[u].x, c0, g, da, db); acc[u].x += da;
+          Meas<M>::grad(a[u].y, b0[u].y, c0, g, da, db); acc[u].y += da;
+          Meas<M>::grad(a[u].z, b0[u].z, c0, g, da, db); acc[u].z += da;
+          Meas<M>::grad(a[u].w, b0[u].w, c0, g, da, db); acc[u].w += da;
+          Meas<M>::grad(a[u].x, b1[u].x, c1, g, da, db); acc[u].x += da;
+          Meas<M>::grad(a[u].y, b1[u].y, c1, g, da, db); acc[u].y += da;
+          Meas<M>::grad(a[u].z, b1[u].z, c1, g, da, db); acc[u].z += da;
+          Meas<M>::grad(a[u].w, b1[u].w, c1, g, da, db); acc[u].w += da;
+        }
+      }
+    }
+  }
+  // neighbour role: r is neighbour n of output o; a = x at o's centre (the zero pixel if padded).  The
+  // (row reader, column reader) pairs are walked as one flat list, two at a time.
+  const unsigned tot = ny * nx;
+  for (unsigned e = 0; e < tot; e += 2) {
+    int jj[2];
+    unsigned pcs[2];
+    bool ok[2];
+    Coef cc[2];
+#pragma unroll
+    for (int v = 0; v < 2; ++v) {
+      const unsigned ee = min(e + v, tot - 1);
+      const unsigned iy = (unsigned)fdivi((int)ee, (int)nx), ix = ee - iy * nx;
+      const uint2 ey = yrow[iy], ex = xrow[ix];
+      const unsigned tap = (ey.y >> 20) + (ex.y >> 20);
+      ok[v] = e + v < tot && !(iy < nyc && ix < nxc);  // centre tap x centre tap was the centre role
+      jj[v] = (int)(ey.x + ex.x) - (tap > mid ? Os : 0);
+      jj[v] = tap == mid ? 0 : jj[v];                    // (that pair's index is not a neighbour index: stay in range)
+      pcs[v] = min((ey.y & 0xFFFFFu) + (ex.y & 0xFFFFFu), zpix);
+      cc[v] = load_coef<M>(cf, ON, jj[v]);
+    }
+    float4 a0[QB], a1[QB];
+#pragma unroll
+    for (int u = 0; u < QB; ++u) {
+      a0[u] = slab[u][pcs[0]];
+      a1[u] = slab[u][pcs[1]];
+    }
+    if (ok[0]) {
+#pragma unroll
+      for (int u = 0; u < QB; ++u) {
+        float da, db;
+        Meas<M>::grad(a0[u].x, a[u].x, cc[0], g, da, db); acc[u].x += db;
+        Meas<M>::grad(a0[u].y, a[u].y, cc[0], g, da, db); acc[u].y += db;
+        Meas<M>::grad(a0[u].z, a[u].z, cc[0], g, da, db); acc[u].z += db;
+        Meas<M>::grad(a0[u].w, a[u].w, cc[0], g, da, db); acc[u].w += db;
+      }
+    }
+    if (ok[1]) {
+#pragma unroll
+      for (int u = 0; u < QB; ++u) {
+        float da, db;
+        Meas<M>::grad(a1[u].x, a[u].x, cc[1], g, da, db); acc[u].x += db;
+        Meas<M>::grad(a1[u].y, a[u].y, cc[1], g, da, db); acc[u].y += db;
+        Meas<M>::grad(a1[u].z, a[u].z, cc[1], g, da, db); acc[u].z += db;
+        Meas<M>::grad(a1[u].w, a[u].w, cc[1], g, da, db); acc[u].w += db;
+      }
+    }
+  }
+}
+
 template <int M, int QB>
 __global__ void __launch_bounds__(512) bwd_gather(const KP g, const GatherLds L, const void* __restrict__ x,
                                                   const void* __restrict__ go, const void* __restrict__ out,
@@ -316,50 +404,7 @@ __global__ void __launch_bounds__(512) bwd_gather(const KP g, const GatherLds L,
       }
       const uint2* yrow = yl + ry * L.capY;
       const uint2* xrow = xl + rx * L.capX;
-      const unsigned ycw = yc[ry], xcw = xc[rx];
-      const unsigned ny = ycw & 0xFFFFu, nx = xcw & 0xFFFFu, nyc = ycw >> 16, nxc = xcw >> 16;
-      // centre role: r is the centre of output o (exactly one for the usual geometries, none or several
-      // when stride > 1 or the padding exceeds the kernel radius)
-      for (unsigned iy = 0; iy < nyc; ++iy) {
-        const uint2 ey = yrow[iy];
-        for (unsigned ix = 0; ix < nxc; ++ix) {
-          const uint2 ex = xrow[ix];
-          for (int n = 0, j = (int)(ey.x + ex.x) - (int)mid * g.O; n < g.N; ++n, j += g.O) {
-            const unsigned q = nbq[j];
-            const Coef c = load_coef<M>(cf, ON, j);
-#pragma unroll
-            for (int u = 0; u < QB; ++u) {
-              const float4 bv = slab[u][q];
-              float da, db;
-              Meas<M>::grad(a[u].x, bv.x, c, g, da, db); acc[u].x += da;
-              Meas<M>::grad(a[u].y, bv.y, c, g, da, db); acc[u].y += da;
-              Meas<M>::grad(a[u].z, bv.z, c, g, da, db); acc[u].z += da;
-              Meas<M>::grad(a[u].w, bv.w, c, g, da, db); acc[u].w += da;
-            }
-          }
-        }
-      }
-      // neighbour role: r is neighbour n of output o; a = x at o's centre (the zero pixel if padded)
-      for (unsigned iy = 0; iy < ny; ++iy) {
-        const uint2 ey = yrow[iy];
-        for (unsigned ix = 0; ix < nx; ++ix) {
-          if (iy < nyc && ix < nxc) continue;  // centre tap x centre tap: handled above
-          const uint2 ex = xrow[ix];
-          const unsigned tap = (ey.y >> 20) + (ex.y >> 20);
-          const int j = (int)(ey.x + ex.x) - (tap > mid ? g.O : 0);
-          const unsigned pc = min((ey.y & 0xFFFFFu) + (ex.y & 0xFFFFFu), (unsigned)g.P);
-          const Coef c = load_coef<M>(cf, ON, j);
-#pragma unroll
-          for (int u = 0; u < QB; ++u) {
-            const float4 av = slab[u][pc];
-            float da, db;
-            Meas<M>::grad(av.x, a[u].x, c, g, da, db); acc[u].x += db;
-            Meas<M>::grad(av.y, a[u].y, c, g, da, db); acc[u].y += db;
-            Meas<M>::grad(av.z, a[u].z, c, g, da, db); acc[u].z += db;
-            Meas<M>::grad(av.w, a[u].w, c, g, da, db); acc[u].w += db;
-          }
-        }
-      }
+      gather_item<M, QB>(g, slab, a, acc, yrow, xrow, yc[ry], xc[rx], cf, ON, nbq, g.O, (unsigned)g.P, mid);
 #pragma unroll
       for (int u = 0; u < QB; ++u) {
         const int cq = qb * QB + u;
@@ -563,47 +608,7 @@ __global__ void __launch_bounds__(512) bwd_gather_banded(const KP g, const BandL
       }
       const uint2* yrow = yl + ryl * L.capY;
       const uint2* xrow = xl + rx * L.capX;
-      const unsigned ycw = yc[ryl], xcw = xc[rx];
-      const unsigned ny = ycw & 0xFFFFu, nx = xcw & 0xFFFFu, nyc = ycw >> 16, nxc = xcw >> 16;
-      for (unsigned iy = 0; iy < nyc; ++iy) {  // centre role
-        const uint2 ey = yrow[iy];
-        for (unsigned ix = 0; ix < nxc; ++ix) {
-          const uint2 ex = xrow[ix];
-          for (int n = 0, j = (int)(ey.x + ex.x) - (int)mid * Ol; n < g.N; ++n, j += Ol) {
-            const unsigned q = nbq[j];
-            const Coef c = load_coef<M>(cf, ON, j);
-#pragma unroll
-            for (int u = 0; u < QB; ++u) {
-              const float4 bv = slab[u][q];
-              float da, db;
-              Meas<M>::grad(a[u].x, bv.x, c, g, da, db); acc[u].x += da;
-              Meas<M>::grad(a[u].y, bv.y, c, g, da, db); acc[u].y += da;
-              Meas<M>::grad(a[u].z, bv.z, c, g, da, db); acc[u].z += da;
-              Meas<M>::grad(a[u].w, bv.w, c, g, da, db); acc[u].w += da;
-            }
-          }
-        }
-      }
-      for (unsigned iy = 0; iy < ny; ++iy) {  // neighbour role
-        const uint2 ey = yrow[iy];
-        for (unsigned ix = 0; ix < nx; ++ix) {
-          if (iy < nyc && ix < nxc) continue;
-          const uint2 ex = xrow[ix];
-          const unsigned tap = (ey.y >> 20) + (ex.y >> 20);
-          const int j = (int)(ey.x + ex.x) - (tap > mid ? Ol : 0);
-          const unsigned pc = min((ey.y & 0xFFFFFu) + (ex.y & 0xFFFFFu), (unsigned)np);
-          const Coef c = load_coef<M>(cf, ON, j);
-#pragma unroll
-          for (int u = 0; u < QB; ++u) {
-            const float4 av = slab[u][pc];
-            float da, db;
-            Meas<M>::grad(av.x, a[u].x, c, g, da, db); acc[u].x += db;
-            Meas<M>::grad(av.y, a[u].y, c, g, da, db); acc[u].y += db;
-            Meas<M>::grad(av.z, a[u].z, c, g, da, db); acc[u].z += db;
-            Meas<M>::grad(av.w, a[u].w, c, g, da, db); acc[u].w += db;
-          }
-        }
-      }
+      gather_item<M, QB>(g, slab, a, acc, yrow, xrow, yc[ryl], xc[rx], cf, ON, nbq, Ol, (unsigned)np, mid);
 #pragma unroll
       for (int u = 0; u < QB; ++u) {
         const int cq = qb * QB + u;
