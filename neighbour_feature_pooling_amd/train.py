@@ -64,6 +64,9 @@ def main():
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32")
     ap.add_argument("--nfp-radius", type=int, default=1)
     ap.add_argument("--nfp-measure", default="cosine")
+    ap.add_argument("--channels-last", action="store_true", help="NHWC activations and weights: MIOpen's NHWC "
+                    "convolutions, and NFP reads the channels-last feature map in place")
+    ap.add_argument("--autotune", action="store_true", help="torch.backends.cudnn.benchmark: MIOpen find mode")
     ap.add_argument("--cpu", action="store_true", help="gloo on CPU (plumbing test)")
     ap.add_argument("--backend", default=None, help="override the process-group backend (gloo lets several "
                     "ranks share one GPU for rehearsal; RCCL refuses that)")
@@ -88,10 +91,15 @@ def main():
     if a.nfp_measure == "norm":
         ctor["p"] = 2
     net = build(a.model, a.classes, a.in_chans, a.image, NFPPooling(C, **ctor), dev, dtype)
+    torch.backends.cudnn.benchmark = bool(a.autotune)
+    if a.channels_last:
+        net = net.to(memory_format=torch.channels_last)
     if world > 1:
         net = DDP(net, device_ids=None if a.cpu else [local], gradient_as_bucket_view=True)
     step, _ = make_step(net)
     x, y = synthetic_batch(a.batch, a.in_chans, a.image, a.classes, dev, dtype, seed=1000 + rank)
+    if a.channels_last:
+        x = x.contiguous(memory_format=torch.channels_last)
     for _ in range(a.warmup):
         step(x, y)
     if not a.cpu:
@@ -110,7 +118,8 @@ def main():
         print(json.dumps({"model": a.model, "n_gpus": world, "batch_per_gpu": a.batch, "image": a.image,
                           "dtype": a.dtype, "ms_per_step": round(dt * 1e3, 3),
                           "images_per_s": round(world * a.batch / dt, 1), "loss": round(float(loss), 4),
-                          "nfp": f"{a.nfp_measure} R={a.nfp_radius}"}))
+                          "nfp": f"{a.nfp_measure} R={a.nfp_radius}",
+                          "layout": "channels_last" if a.channels_last else "nchw", "autotune": bool(a.autotune)}))
     if world > 1:
         dist.destroy_process_group()
 
