@@ -604,3 +604,63 @@ def test_large_maps_use_the_banded_backward(B, C, H, W, ctor, dev):
     gref, = torch.autograd.grad(ref, x64, go.double())
     assert rel_err(out.detach().cpu().numpy(), ref.detach().cpu().numpy()) <= TOL
     assert rel_err(gx.cpu().numpy(), gref.cpu().numpy()) <= 2 * TOL
+
+
+def test_random_geometry_stress(dev, monkeypatch):
+    """A few hundred random (geometry, measure, layout) draws through the default dispatch and through the forced
+    row-banded backward, each against the float64 formulation: the index tables of nfp_gather.h are built
+    analytically, this is the net under that arithmetic."""
+    import random
+    from neighbour_feature_pooling_amd import NFPPooling, _abi
+    from neighbour_feature_pooling_amd._host import nfp_host
+    rnd = random.Random(77)
+    measures = sorted(HIP_MEASURES)
+    done, variants = 0, set()
+    for it in range(400):
+        H, W = rnd.randint(1, 22), rnd.randint(1, 22)
+        R, stride, dil = rnd.choice([1, 1, 2, 3]), rnd.choice([1, 1, 2, 3]), rnd.choice([1, 1, 2])
+        pad = rnd.choice([0, R, R * dil, R * dil + 1, 1])
+        mode = rnd.choice(["reflect", "zeros", "replicate", "circular"])
+        k = 2 * R + 1
+        if H + 2 * pad < dil * (k - 1) + 1 or W + 2 * pad < dil * (k - 1) + 1:
+            continue
+        if (mode == "reflect" and (pad >= H or pad >= W)) or (mode == "circular" and (pad > H or pad > W)):
+            continue
+        meas = rnd.choice(measures)
+        B, C = rnd.randint(1, 3), rnd.choice([4, 5, 6, 8, 13, 32])   # (1-3 channels: several measures degenerate to ~eps)
+        ctor = dict(R=R, measure=meas, padding=pad, stride=stride, dilation=dil, padding_mode=mode,
+                    similarity=rnd.random() < 0.7)
+        if meas == "norm":
+            ctor["p"] = rnd.choice([1, 2, 3])
+        m = NFPPooling(C, **ctor)
+        g = torch.Generator().manual_seed(it)
+        x = (torch.rand(B, C, H, W, generator=g) + 0.25).to(dev)
+        if rnd.random() < 0.3:
+            x = x.contiguous(memory_format=torch.channels_last)
+        x.requires_grad_(True)
+        monkeypatch.delenv("NFP_BWD_BANDS", raising=False)
+        out = m(x)
+        go = torch.randn(out.shape, generator=g).to(dev)
+        gx, = torch.autograd.grad(out, x, go, retain_graph=True)
+        variants.add(_abi.load().nfp_last_variant().decode().split("<")[0])
+        monkeypatch.setenv("NFP_BWD_BANDS", "2")
+        gxb, = torch.autograd.grad(out, x, go)
+        variants.add(_abi.load().nfp_last_variant().decode().split("<")[0])
+        x64 = x.detach().double().requires_grad_(True)
+        ref = nfp_host(x64, m.config)
+        gref, = torch.autograd.grad(ref, x64, go.double())
+        what = (it, tuple(x.shape), ctor)
+        # an index error is an O(1) error; float32-vs-float64 conditioning of a few measures on few channels is not
+        tol_g = 2e-4 if meas in ("pearson", "hellinger", "squaredchord", "jeffrey", "smith") else 5e-5
+        o_, r_ = out.detach().cpu().numpy(), ref.detach().cpu().numpy()
+        assert same_nan_pattern(o_, r_), what
+        assert rel_err(np.nan_to_num(o_), np.nan_to_num(r_)) <= 1e-4, what
+        gr_ = gref.cpu().numpy()
+        for g_ in (gx.cpu().numpy(), gxb.cpu().numpy()):
+            # a neighbour tap that folds onto its own centre has distance exactly 0: sqrt'(0) * 0 is NaN in torch
+            # and here, at the same elements
+            assert same_nan_pattern(g_, gr_), what
+            assert rel_err(np.nan_to_num(g_), np.nan_to_num(gr_)) <= tol_g, what
+        done += 1
+    assert done > 250
+    assert {"bwd_gather", "bwd_gather_banded", "bwd_fast"} <= variants, variants
