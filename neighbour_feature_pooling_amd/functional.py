@@ -89,6 +89,16 @@ def _plan(x, cfg):
     return plan
 
 
+def _raw_stream(dev):
+    """hipStream_t of torch's current stream on `dev` as an int.  torch.cuda.current_stream() builds a Stream
+    object through several Python layers (~20 us, more than both kernels' launch cost); the raw accessor that
+    Inductor-generated code uses is a single C call."""
+    try:
+        return torch._C._cuda_getCurrentRawStream(dev.index)
+    except AttributeError:  # pragma: no cover - older / newer torch without the private accessor
+        return torch.cuda.current_stream(dev).cuda_stream
+
+
 class _on_device:
     """`with torch.cuda.device(dev)` only when dev is not already current (the common case costs nothing)."""
 
@@ -115,7 +125,7 @@ class _NfpHip(torch.autograd.Function):
         with _on_device(x.device):
             out = torch.empty(oshape, dtype=x.dtype, device=x.device)
             saved = torch.empty(max(ns, 0), dtype=torch.float32, device=x.device)
-            stream = torch.cuda.current_stream().cuda_stream
+            stream = _raw_stream(x.device)
             _abi.check(L.nfp_forward(ctypes.byref(d), x.data_ptr(), out.data_ptr(),
                                      saved.data_ptr() if ns > 0 else None, stream))
         ctx.desc = d
@@ -133,7 +143,7 @@ class _NfpHip(torch.autograd.Function):
             go = go.to(x.dtype)
         with _on_device(x.device):
             gx = torch.empty_like(x)  # same strides as x (dense NCHW or channels-last)
-            stream = torch.cuda.current_stream().cuda_stream
+            stream = _raw_stream(x.device)
             _abi.check(L.nfp_backward(ctypes.byref(d), x.data_ptr(), go.data_ptr(), out.data_ptr(),
                                       saved.data_ptr() if saved.numel() else None, gx.data_ptr(), stream))
         return gx, None
@@ -152,7 +162,7 @@ class _NfpPoolHip(torch.autograd.Function):
             nfpm = torch.empty(B, N, dtype=torch.float32, device=x.device)
             out_map = torch.empty(B, N, Ho, Wo, dtype=x.dtype, device=x.device)
             saved = torch.empty(max(ns, 0), dtype=torch.float32, device=x.device)
-            stream = torch.cuda.current_stream().cuda_stream
+            stream = _raw_stream(x.device)
             _abi.check(L.nfp_pool_forward(ctypes.byref(d), x.data_ptr(), gap.data_ptr(), nfpm.data_ptr(),
                                           out_map.data_ptr(), saved.data_ptr() if ns > 0 else None, stream))
         ctx.desc = d
@@ -168,7 +178,7 @@ class _NfpPoolHip(torch.autograd.Function):
         g_nfpm = g_nfpm.contiguous().float()
         with _on_device(x.device):
             gx = torch.empty_like(x)
-            stream = torch.cuda.current_stream().cuda_stream
+            stream = _raw_stream(x.device)
             _abi.check(L.nfp_pool_backward(ctypes.byref(ctx.desc), x.data_ptr(), g_gap.data_ptr(), g_nfpm.data_ptr(),
                                            out_map.data_ptr(), saved.data_ptr() if saved.numel() else None,
                                            gx.data_ptr(), stream))
