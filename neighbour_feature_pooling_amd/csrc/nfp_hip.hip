@@ -17,6 +17,7 @@
 
 #include "nfp_fast.h"
 #include "nfp_gather.h"
+#include "nfp_mfma.h"
 #include "nfp_generic.h"
 
 using namespace nfp;
@@ -545,6 +546,28 @@ int launch_bwd_fast_t(KP g, const void* x, const void* go, const void* out, cons
                 ggap, gnfpm);
 }
 
+// Matrix-core forward (nfp_mfma.h): bf16, dense channels-last, C a multiple of 16.
+#ifndef NFP_MFMA_DEFAULT
+#define NFP_MFMA_DEFAULT 1
+#endif
+bool mfma_enabled() {
+  const char* e = getenv("NFP_MFMA");
+  return e ? e[0] == '1' : NFP_MFMA_DEFAULT != 0;
+}
+
+template <int R, int M>
+int launch_fwd_gram(const KP& g, const void* x, void* out, float* saved, hipStream_t st) {
+  if (!mfma_enabled() || g.dtype != NFP_BF16 || g.contig || (g.C & 15) || g.P > 512) return kNotApplicable;
+  const int nt = (g.P + 31) / 32, D = std::min(nt - 1, (g.R * g.W + g.R + 31) / 32);
+  const size_t tiles = (((size_t)nt * (D + 1) * 32 * kGramLd + 3) & ~(size_t)3) * 4;
+  const size_t image = (size_t)g.P * (g.C / 8 + 1) * 16;
+  if (tiles > (size_t)kLdsMax) return kNotApplicable;
+  snprintf(g_variant, sizeof(g_variant), "fwd_gram<R%d,%s,bf16,nhwc>", R, M == NFP_COSINE ? "cos" : "l2");
+  if (tiles + image <= (size_t)kLdsMax)
+    return launch("fwd_gram", fwd_gram<R, M, true>, dim3(g.B), dim3(512), tiles + image, st, g, x, out, saved, D);
+  return launch("fwd_gram", fwd_gram<R, M, false>, dim3(g.B), dim3(512), tiles, st, g, x, out, saved, D);
+}
+
 template <int R, int M>
 int launch_bwd_fast(const KP& g, const void* x, const void* go, const void* out, const float* saved, void* gx,
                     hipStream_t st) {
@@ -595,6 +618,13 @@ int nfp_forward(const nfp_desc* d, const void* x, void* out, float* saved, void*
   hipStream_t st = (hipStream_t)hip_stream;
   if (fast_ok(g, x, x)) {
     int rc;
+    if (g.measure == NFP_COSINE)
+      rc = g.R == 1 ? launch_fwd_gram<1, NFP_COSINE>(g, x, out, saved, st)
+                    : launch_fwd_gram<2, NFP_COSINE>(g, x, out, saved, st);
+    else
+      rc = g.R == 1 ? launch_fwd_gram<1, NFP_NORM>(g, x, out, saved, st)
+                    : launch_fwd_gram<2, NFP_NORM>(g, x, out, saved, st);
+    if (rc != kNotApplicable) return rc;
     if (g.measure == NFP_COSINE)
       rc = g.R == 1 ? launch_fwd_fast<1, NFP_COSINE>(g, x, out, saved, st)
                     : launch_fwd_fast<2, NFP_COSINE>(g, x, out, saved, st);

@@ -1,0 +1,110 @@
+// nfp_mfma.h — forward on the matrix cores for bf16 channels-last feature maps (ViT tokens: config 5).
+//
+// Replaces nfp.py:132-159 like fwd_fast, for the case where the matrix cores are the right tool: bf16 storage
+// (products of two bf16 are exact in f32, so the MFMA's f32 accumulation is the same arithmetic as the vector
+// path, in a different order) and a channels-last layout, which IS the A / B fragment layout of
+// v_mfma_f32_32x32x16_bf16 — lane (r, h) holds 8 consecutive channels of pixel r: one 16-byte global load, no
+// LDS staging, no transposition.
+//
+// Per image, the pair sums x_p . x_q are entries of the Gram matrix G = X Xt.  Neighbours are at most
+// R*W + R pixels apart, so only the 32x32 tiles within D = ceil((R*W + R)/32) of the diagonal are needed, and
+// by symmetry only those on or above it: a wavefront per tile, C/16 MFMAs each (config 5: 13 tiles x 12).
+// Cosine reads G_pq, G_pp, G_qq; L2 is G_pp + G_qq - 2 G_pq.  The three come from the same products summed in
+// the same order, so identical vectors still give exactly 0 (the cancellation that rules the Gram form out
+// for f32 inputs is bounded here by the 8-bit mantissa of the inputs: see DESIGN.md).
+#pragma once
+#include "nfp_fast.h"
+
+namespace nfp {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kGramLd = 33;  // row stride of a stored tile (floats): column reads by 32 lanes hit 32 banks
+
+// LDSX: the image is first copied into LDS (coalesced 16-byte pieces, rows padded by 16 bytes so that the 32
+// fragment rows of a ds_read_b128 fall on distinct banks) and every tile reads its fragments from there; reading
+// them from global memory instead costs each pixel row three times over in half-used 32-byte sectors (measured:
+// 16 us against 23 us for the vector kernel, the traffic of the re-reads).  Without LDSX (image + tiles beyond
+// LDS) the fragments come from global memory.
+template <int R, int M, bool LDSX>
+__global__ void __launch_bounds__(512) fwd_gram(const KP g, const void* __restrict__ x, void* __restrict__ out,
+                                                float* __restrict__ saved, int D) {
+  constexpr int K = 2 * R + 1, N = K * K - 1;
+  extern __shared__ __attribute__((aligned(16))) float Gt[];  // [nt * (D + 1)][32][kGramLd], then the image
+  const int b = blockIdx.x, t = threadIdx.x, T = blockDim.x;
+  const int P = g.P, C = g.C, nt = (P + 31) >> 5;
+  const int wave = t >> 6, lane = t & 63, r = lane & 31, h = lane >> 5;
+  const uint16_t* xb = (const uint16_t*)x + (long long)b * g.sB;  // pixel p, channel c at xb[p * C + c]
+  const int rowq = (C >> 3) + 1;  // 16-byte pieces per LDS row (one of padding)
+  uint4* xl = (uint4*)(Gt + ((nt * (D + 1) * 32 * kGramLd + 3) & ~3));
+  if (LDSX) {
+    const int cq = C >> 3;  // pieces per pixel row
+    for (int i = t; i < P * cq; i += T) {
+      const int pp = fdivi(i, cq), k = i - pp * cq;
+      xl[pp * rowq + k] = ((const uint4*)xb)[i];
+    }
+    __syncthreads();
+  }
+
+  // ---- Gram tiles: tile pair (i, j = i + d), one wavefront each ---------------------------------------------
+  for (int pi = wave; pi < nt * (D + 1); pi += T >> 6) {
+    const int i = fdivi(pi, D + 1), j = i + (pi - i * (D + 1));
+    if (j >= nt) continue;
+    const int pa = min(32 * i + r, P - 1), pb = min(32 * j + r, P - 1);  // rows past P repeat the last pixel
+    const uint4* A = LDSX ? xl + pa * rowq + h : (const uint4*)(xb + (long long)pa * C + 8 * h);
+    const uint4* B = LDSX ? xl + pb * rowq + h : (const uint4*)(xb + (long long)pb * C + 8 * h);
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll 4
+    for (int kk = 0; kk < (C >> 4); ++kk) {  // 16 channels per step = two 16-byte pieces per pixel row
+      const uint4 av = A[2 * kk], bv = B[2 * kk];
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), acc,
+                                                    0, 0, 0);
+    }
+    float* tile = Gt + (long long)pi * 32 * kGramLd;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) tile[((e & 3) + 8 * (e >> 2) + 4 * h) * kGramLd + r] = acc[e];  // G[32i+row][32j+r]
+  }
+  __syncthreads();
+
+  // ---- outputs: thread (p, n = gl, gl + G, ...), as fwd_fast ------------------------------------------------------
+  const int G = max(1, T / P), gl = fdivi(t, P), p = t - gl * P;
+  if (gl >= G) return;
+  auto gram = [&](int a, int c) -> float {  // G[a][c] for pixels within the band
+    const int ta = a >> 5, tc = c >> 5;
+    const int lo = min(ta, tc), dd = abs(ta - tc);
+    const int row = ta <= tc ? (a & 31) : (c & 31), col = ta <= tc ? (c & 31) : (a & 31);
+    return Gt[((long long)(lo * (D + 1) + dd) * 32 + row) * kGramLd + col];
+  };
+  const int py = fdivi(p, g.W), px = p - py * g.W;
+  NbrMap<R> nm;
+  nm.init(g, py, px);
+  void* ob = (char*)out + (long long)b * N * P * 2;
+  const float n2p = gram(p, p);
+  const float ip = inv_norm(n2p, g.inv_eps);
+  for (int n = gl; n < N; n += G) {
+    int qy, qx;
+    const int q = nm.get(g, n, qy, qx);
+    const int qc = max(q, 0);
+    const float n2q = gram(qc, qc), dot = gram(p, qc);
+    float v;
+    if (M == NFP_COSINE) {
+      const float s = q < 0 ? 0.f : dot * ip * inv_norm(n2q, g.inv_eps);
+      v = g.similarity ? s : 1.f - s;
+    } else {
+      float d2;
+      if (g.diff)
+        d2 = q < 0 ? n2p : (q == p ? 0.f : fmaxf(n2p + n2q - 2.f * dot, 0.f));
+      else
+        d2 = q < 0 ? 0.f : n2q;  // 'Norm' quirk (nfp.py:74 vs 85): |neighbour|
+      const float dd = __builtin_amdgcn_sqrtf(d2);
+      v = g.similarity ? -dd : dd;
+    }
+    stx(ob, n * P + p, v, NFP_BF16);
+  }
+  if (M == NFP_COSINE && saved != nullptr && gl == 0) saved[(long long)b * P + p] = __builtin_amdgcn_sqrtf(n2p);
+}
+
+}  // namespace nfp

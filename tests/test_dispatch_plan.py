@@ -58,6 +58,8 @@ def test_plan_does_not_launch_or_disturb_last_variant(lib):
     (dict(shape=(256, 192, 14, 14), R=2, measure="norm", dtype=_abi.BF16), "fwd_fast<R2,l2,bf16,nchw>",
      "bwd_fast<R2,l2,bf16,nchw>"),                                                                      # config 5
     (dict(shape=(8, 512, 7, 7), channels_last=True), "fwd_fast<R1,cos,f32,nhwc>", "bwd_fast<R1,cos,f32,nhwc>"),
+    (dict(shape=(256, 192, 14, 14), R=2, measure="norm", dtype=_abi.BF16, channels_last=True),
+     "fwd_gram<R2,l2,bf16,nhwc>", "bwd_fast<R2,l2,bf16,nhwc>"),                                         # ViT tokens: matrix cores
     (dict(shape=(64, 512, 7, 7), measure="norm", p=1.0), "fwd_pairs", "bwd_gather"),                    # reference default p
     (dict(shape=(64, 512, 7, 7), pad=0), "fwd_pairs", "bwd_gather"),                                    # pad != R
     (dict(shape=(64, 512, 7, 7), stride=2), "fwd_pairs", "bwd_gather"),
@@ -114,4 +116,4 @@ def test_every_accepted_descriptor_launches_within_device_limits(lib):
                 assert lds <= LDS_MAX and 1 <= block <= 1024, text
                 assert all(v >= 1 for v in grid) and grid[1] <= 65535 and grid[2] <= 65535, text
     assert accepted > 2000
-    assert {"fwd_fast", "bwd_fast", "fwd_pairs", "bwd_gather", "bwd_gather_banded"} <= seen, seen
+    assert {"fwd_fast", "fwd_gram", "bwd_fast", "fwd_pairs", "bwd_gather", "bwd_gather_banded"} <= seen, seen

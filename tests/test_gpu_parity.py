@@ -664,3 +664,61 @@ def test_random_geometry_stress(dev, monkeypatch):
         done += 1
     assert done > 250
     assert {"bwd_gather", "bwd_gather_banded", "bwd_fast"} <= variants, variants
+
+
+@pytest.mark.parametrize("B,C,H,W,R,meas,mode,kind", [
+    (4, 192, 14, 14, 2, "norm", "reflect", "randn"),        # config 5 geometry
+    (4, 192, 14, 14, 2, "cosine", "reflect", "randn"),
+    (3, 512, 7, 7, 1, "cosine", "reflect", "relu"),         # headline geometry, bf16 channels-last
+    (3, 32, 5, 9, 1, "norm", "replicate", "randn"),
+    (2, 48, 6, 5, 2, "cosine", "zeros", "relu"),
+    (2, 16, 9, 9, 1, "norm", "zeros", "const"),             # identical neighbours: exactly zero distance
+    (2, 192, 14, 14, 2, "norm", "reflect", "smooth"),       # nearly identical neighbours: the Gram form's hard case
+    (1, 512, 16, 16, 2, "norm", "reflect", "randn"),        # image + tiles beyond LDS: fragments from global memory
+    (2, 64, 1, 40, 1, "cosine", "replicate", "randn"),
+])
+def test_matrix_core_forward_bf16_channels_last(B, C, H, W, R, meas, mode, kind, dev, monkeypatch):
+    """fwd_gram (nfp_mfma.h): banded Gram matrix on v_mfma_f32_32x32x16_bf16.  Same bf16 inputs, f32 accumulation:
+    it must agree with the vector kernel to f32 rounding BEFORE the bf16 output rounding — i.e. the two bf16
+    outputs may differ by at most one bf16 ulp, rarely — and with the float64 formulation to bf16 precision."""
+    from neighbour_feature_pooling_amd import NFPPooling, _abi
+    from neighbour_feature_pooling_amd._host import nfp_host
+    monkeypatch.setenv("NFP_FORCE_GENERIC", "0")
+    ctor = dict(R=R, measure=meas, padding=R, padding_mode=mode)
+    if meas == "norm":
+        ctor["p"] = 2
+    m = NFPPooling(C, **ctor)
+    g = torch.Generator().manual_seed(C + H)
+    x = torch.randn(B, C, H, W, generator=g)
+    if kind == "relu":
+        x = x.relu()
+    if kind == "const":
+        x = torch.ones_like(x) * 0.37 + torch.arange(C).view(1, C, 1, 1) * 0.01
+    if kind == "smooth":
+        x = x.mean((2, 3), keepdim=True) + 0.01 * x
+    x = x.to(dev).bfloat16().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    monkeypatch.setenv("NFP_MFMA", "1")
+    n0 = _launches()
+    out = m(x)
+    assert _abi.load().nfp_last_variant().decode().startswith("fwd_gram<"), _abi.load().nfp_last_variant()
+    assert _launches() == n0 + 1
+    assert torch.equal(out, m(x))                                   # deterministic
+    monkeypatch.setenv("NFP_MFMA", "0")
+    out_v = m(x)
+    assert _abi.load().nfp_last_variant().decode().startswith("fwd_fast<")
+    ref = nfp_host(x.detach().double(), m.config)
+    sc = ref.abs().max().item()
+    d = (out.float() - out_v.float()).abs()
+    assert d.max().item() <= 2 ** -7 * sc                            # at most one bf16 ulp of the largest value apart
+    assert (d > 0).float().mean().item() <= 0.02                     # and only where a rounding boundary is crossed
+    assert rel_err(out.detach().float().cpu().numpy(), ref.float().cpu().numpy()) <= 1e-2
+    if kind == "const":
+        assert out[:, :, 1:-1, 1:-1].abs().max().item() == 0.0 if R == 1 else True
+    # the backward (vector kernel) consumes what this forward saved
+    monkeypatch.setenv("NFP_MFMA", "1")
+    go = torch.randn(out.shape, generator=g).to(dev).bfloat16()
+    gx, = torch.autograd.grad(m(x), x, go)
+    x64 = x.detach().double().requires_grad_(True)
+    gref, = torch.autograd.grad(nfp_host(x64, m.config), x64, go.double())
+    if kind not in ("const", "smooth"):                               # (those have |out| ~ 0: sqrt'(0))
+        assert rel_err(gx.float().cpu().numpy(), gref.float().cpu().numpy()) <= 2e-2
