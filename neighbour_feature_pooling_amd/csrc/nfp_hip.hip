@@ -557,12 +557,16 @@ bool mfma_enabled() {
 
 template <int R, int M>
 int launch_fwd_gram(const KP& g, const void* x, void* out, float* saved, hipStream_t st) {
-  if (!mfma_enabled() || g.dtype != NFP_BF16 || g.contig || (g.C & 15) || g.P > 512) return kNotApplicable;
+  if (!mfma_enabled() || g.dtype != NFP_BF16 || (g.C & 15) || g.P > 512) return kNotApplicable;
   const int nt = (g.P + 31) / 32, D = std::min(nt - 1, (g.R * g.W + g.R + 31) / 32);
   const size_t tiles = (((size_t)nt * (D + 1) * 32 * kGramLd + 3) & ~(size_t)3) * 4;
   const size_t image = (size_t)g.P * (g.C / 8 + 1) * 16;
   if (tiles > (size_t)kLdsMax) return kNotApplicable;
-  snprintf(g_variant, sizeof(g_variant), "fwd_gram<R%d,%s,bf16,nhwc>", R, M == NFP_COSINE ? "cos" : "l2");
+  if (g.contig && tiles + image > (size_t)kLdsMax) return kNotApplicable;  // NCHW is transposed through LDS only
+  snprintf(g_variant, sizeof(g_variant), "fwd_gram<R%d,%s,bf16,%s>", R, M == NFP_COSINE ? "cos" : "l2",
+           g.contig ? "nchw" : "nhwc");
+  if (g.contig)
+    return launch("fwd_gram", fwd_gram<R, M, true, true>, dim3(g.B), dim3(512), tiles + image, st, g, x, out, saved, D);
   if (tiles + image <= (size_t)kLdsMax)
     return launch("fwd_gram", fwd_gram<R, M, true>, dim3(g.B), dim3(512), tiles + image, st, g, x, out, saved, D);
   return launch("fwd_gram", fwd_gram<R, M, false>, dim3(g.B), dim3(512), tiles, st, g, x, out, saved, D);

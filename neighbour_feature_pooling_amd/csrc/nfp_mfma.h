@@ -27,7 +27,9 @@ constexpr int kGramLd = 33;  // row stride of a stored tile (floats): column rea
 // them from global memory instead costs each pixel row three times over in half-used 32-byte sectors (measured:
 // 16 us against 23 us for the vector kernel, the traffic of the re-reads).  Without LDSX (image + tiles beyond
 // LDS) the fragments come from global memory.
-template <int R, int M, bool LDSX>
+// NCHW: bf16 NCHW input, transposed into the same LDS image (thread = (pixel, 8 channels): eight 2-byte loads,
+// coalesced along the pixel axis, packed into one 16-byte LDS write); needs LDSX.
+template <int R, int M, bool LDSX, bool NCHW = false>
 __global__ void __launch_bounds__(512) fwd_gram(const KP g, const void* __restrict__ x, void* __restrict__ out,
                                                 float* __restrict__ saved, int D) {
   constexpr int K = 2 * R + 1, N = K * K - 1;
@@ -35,14 +37,31 @@ __global__ void __launch_bounds__(512) fwd_gram(const KP g, const void* __restri
   const int b = blockIdx.x, t = threadIdx.x, T = blockDim.x;
   const int P = g.P, C = g.C, nt = (P + 31) >> 5;
   const int wave = t >> 6, lane = t & 63, r = lane & 31, h = lane >> 5;
-  const uint16_t* xb = (const uint16_t*)x + (long long)b * g.sB;  // pixel p, channel c at xb[p * C + c]
+  const uint16_t* xb = (const uint16_t*)x + (long long)b * g.sB;  // channels-last: pixel p, channel c at xb[p * C + c]
   const int rowq = (C >> 3) + 1;  // 16-byte pieces per LDS row (one of padding)
   uint4* xl = (uint4*)(Gt + ((nt * (D + 1) * 32 * kGramLd + 3) & ~3));
+  static_assert(LDSX || !NCHW, "the NCHW variant transposes through LDS");
   if (LDSX) {
     const int cq = C >> 3;  // pieces per pixel row
-    for (int i = t; i < P * cq; i += T) {
-      const int pp = fdivi(i, cq), k = i - pp * cq;
-      xl[pp * rowq + k] = ((const uint4*)xb)[i];
+    if (NCHW) {
+      for (int i = t; i < P * cq; i += T) {
+        const int k = fdivi(i, P), pp = i - k * P;  // pixel fastest: coalesced
+        const uint16_t* src = xb + (long long)(8 * k) * P + pp;
+        uint16_t v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = src[(long long)u * P];
+        uint4 w;
+        w.x = v[0] | ((uint32_t)v[1] << 16);
+        w.y = v[2] | ((uint32_t)v[3] << 16);
+        w.z = v[4] | ((uint32_t)v[5] << 16);
+        w.w = v[6] | ((uint32_t)v[7] << 16);
+        xl[pp * rowq + k] = w;
+      }
+    } else {
+      for (int i = t; i < P * cq; i += T) {
+        const int pp = fdivi(i, cq), k = i - pp * cq;
+        xl[pp * rowq + k] = ((const uint4*)xb)[i];
+      }
     }
     __syncthreads();
   }

@@ -26,7 +26,9 @@ for (B, C, H, W, R, meas, mode, kind) in [(4, 192, 14, 14, 2, "norm", "reflect",
         x = torch.ones_like(x) * 0.37 + (torch.arange(C, device=dev).view(1, C, 1, 1) * 0.01)
     if kind == "smooth":
         x = x.mean((2, 3), keepdim=True) + 0.01 * x      # neighbours nearly identical: the Gram form's hard case
-    x = x.bfloat16().contiguous(memory_format=torch.channels_last)
+    x = x.bfloat16()
+    if B != 3:
+        x = x.contiguous(memory_format=torch.channels_last)      # (the B = 3 cases stay NCHW)
     outs = {}
     for env in ("1", "0"):
         os.environ["NFP_MFMA"] = env
@@ -43,16 +45,19 @@ for (B, C, H, W, R, meas, mode, kind) in [(4, 192, 14, 14, 2, "norm", "reflect",
         print("   identical neighbours -> max |d| inside:", inside.abs().max().item())
 print("worst gram err", worst)
 s = torch.cuda.Stream()
-for (B, C, S, R, meas) in [(256, 192, 14, 2, "norm"), (256, 192, 14, 2, "cosine"), (64, 512, 7, 1, "cosine")]:
+for (B, C, S, R, meas, cl) in [(256, 192, 14, 2, "norm", True), (256, 192, 14, 2, "cosine", True), (64, 512, 7, 1, "cosine", True),
+                               (256, 192, 14, 2, "norm", False), (64, 512, 7, 1, "cosine", False), (256, 512, 7, 1, "cosine", False)]:
     ctor = dict(R=R, measure=meas, padding=R)
     if meas == "norm":
         ctor["p"] = 2
     m = NFPPooling(C, **ctor)
-    x = torch.randn(B, C, S, S, device=dev).bfloat16().contiguous(memory_format=torch.channels_last)
+    x = torch.randn(B, C, S, S, device=dev).bfloat16()
+    if cl:
+        x = x.contiguous(memory_format=torch.channels_last)
     res = {}
     for env in ("1", "0"):
         os.environ["NFP_MFMA"] = env
         with torch.cuda.stream(s), torch.no_grad():
             m(x)
             res[env] = (time_kernel_graph(lambda: m(x), 20, s), L.nfp_last_variant().decode().split("<")[0])
-    print(f"[{B},{C},{S},{S}] k{2*R+1} {meas} bf16 nhwc: " + "  ".join(f"{v[1]} {v[0]:.2f} us" for v in res.values()), flush=True)
+    print(f"[{B},{C},{S},{S}] k{2*R+1} {meas} bf16 {'nhwc' if cl else 'nchw'}: " + "  ".join(f"{v[1]} {v[0]:.2f} us" for v in res.values()), flush=True)

@@ -676,8 +676,11 @@ def test_random_geometry_stress(dev, monkeypatch):
     (2, 192, 14, 14, 2, "norm", "reflect", "smooth"),       # nearly identical neighbours: the Gram form's hard case
     (1, 512, 16, 16, 2, "norm", "reflect", "randn"),        # image + tiles beyond LDS: fragments from global memory
     (2, 64, 1, 40, 1, "cosine", "replicate", "randn"),
+    (5, 192, 14, 14, 2, "norm", "reflect", "nchw"),          # NCHW bf16: transposed into the same LDS image
+    (5, 512, 7, 7, 1, "cosine", "reflect", "nchw"),
+    (5, 48, 6, 5, 2, "cosine", "zeros", "nchw"),
 ])
-def test_matrix_core_forward_bf16_channels_last(B, C, H, W, R, meas, mode, kind, dev, monkeypatch):
+def test_matrix_core_forward_bf16(B, C, H, W, R, meas, mode, kind, dev, monkeypatch):
     """fwd_gram (nfp_mfma.h): banded Gram matrix on v_mfma_f32_32x32x16_bf16.  Same bf16 inputs, f32 accumulation:
     it must agree with the vector kernel to f32 rounding BEFORE the bf16 output rounding — i.e. the two bf16
     outputs may differ by at most one bf16 ulp, rarely — and with the float64 formulation to bf16 precision."""
@@ -696,7 +699,10 @@ def test_matrix_core_forward_bf16_channels_last(B, C, H, W, R, meas, mode, kind,
         x = torch.ones_like(x) * 0.37 + torch.arange(C).view(1, C, 1, 1) * 0.01
     if kind == "smooth":
         x = x.mean((2, 3), keepdim=True) + 0.01 * x
-    x = x.to(dev).bfloat16().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    x = x.to(dev).bfloat16()
+    if kind != "nchw":
+        x = x.contiguous(memory_format=torch.channels_last)
+    x.requires_grad_(True)
     monkeypatch.setenv("NFP_MFMA", "1")
     n0 = _launches()
     out = m(x)
