@@ -96,6 +96,10 @@ __device__ unsigned long long* nfp_stamp_buf = nullptr;
 #define NFP_STAMP(id) do { } while (0)
 #endif
 
+// matrix-core operand / accumulator types (v_mfma_f32_32x32x16_bf16: 8 bf16 per lane in, 16 f32 per lane out)
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
 __device__ __forceinline__ float sgnf(float v) { return (float)((v > 0.f) - (v < 0.f)); }
 
 // Per-channel arithmetic of the measures (term / grad, evaluated C*N times per output pixel): hardware

@@ -496,16 +496,192 @@ __global__ void __launch_bounds__(MAXT) fwd_fast(const KP g, const void* __restr
   NFP_STAMP(5);
 }
 
+// ---- backward phase B on the matrix cores (bf16 storage) ----------------------------------------------------
+// grad_x[r][c] = sum_t W[r][t] x[t][c] is a banded GEMM per image: W is the P x K2 window table `Wt` that phase A
+// leaves in LDS, non-zero only for |t - r| <= R*W + R.  For a tile of 32 pixels the summed pixels t span
+// 32 + 2*band (+ alignment) values: KW steps of 16.  Both operands want the SUMMED index contiguous per lane:
+//   Xt [channel][pixel]  bf16  (the image block, transposed on the way in when the tensor is channels-last)
+//   Wd [row pixel][t - ts] bf16, twice: hi = the top 16 bits of the f32 weight, lo = the next 16 (two MFMAs per
+//      step keep 16 significand bits of every weight; the inputs themselves carry 8)
+// and the same two LDS images serve both orientations: A = Xt, B = Wd gives D[channel][pixel] (lanes along
+// pixels: coalesced NCHW stores), A = Wd, B = Xt gives D[pixel][channel] (channels-last stores).
+// Row tiles are processed two at a time (Wd of all of them does not fit next to Xt at config 5's shape).
+__device__ __forceinline__ int odd_up(int v) { return v | 1; }
+
+template <int R, bool NHWC>
+__device__ __forceinline__ void bwd_gemm_phase(const KP& g, const float* Wt, uint4* scratch, const uint16_t* xb,
+                                               uint16_t* gxb, int cb0, int cb1, int t, int T) {
+  constexpr int K = Win<R>::K, K2 = Win<R>::K2;
+  const int P = g.P, C = g.C, band = R * g.W + R, nt = (P + 31) >> 5;
+  const int KW = (32 + 2 * band + 15 + 15) >> 4;            // k-steps that cover a row tile's window after aligning its start
+  const int xq = odd_up(((P + 15) >> 4 << 1) + 1);          // 16-byte pieces per Xt row: P rounded up to 16 pixels, + padding, odd
+  const int wq = odd_up(2 * KW + 1);                        // pieces per Wd row
+  const int ncw = cb1 - cb0;                                // channels of this workgroup (multiple of 32)
+  uint4* Xt = scratch;                                      // [ncw][xq]
+  uint4* Wd = Xt + (long long)ncw * xq;                     // [2 row tiles][hi, lo][32][wq]
+  const int lane = t & 63, wave = t >> 6, nw = T >> 6, r = lane & 31, h = lane >> 5;
+
+  // ---- Xt: 8 consecutive pixels of one channel per 16-byte piece; pixels past P are zero ------------------
+  const int pg = (P + 7) >> 3;
+  if (NHWC) {
+    // 8 pixels x 8 channels per step: eight 16-byte loads (one per pixel), transposed in registers into eight
+    // pieces (one per channel)
+    const int co = ncw >> 3;
+    for (int i = t; i < pg * co; i += T) {
+      const int gq = fdivi(i, co), k = i - gq * co;  // channel octet fastest: coalesced
+      uint4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int pp = min(8 * gq + u, P - 1);
+        v[u] = *(const uint4*)(xb + (long long)pp * C + cb0 + 8 * k);
+        if (8 * gq + u >= P) v[u] = make_uint4(0, 0, 0, 0);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {  // channel 8k + j: its 16 bits of every pixel's piece
+        uint32_t e[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const uint32_t wd = (j >> 1) == 0 ? v[u].x : ((j >> 1) == 1 ? v[u].y : ((j >> 1) == 2 ? v[u].z : v[u].w));
+          e[u] = (j & 1) ? (wd >> 16) : (wd & 0xFFFFu);
+        }
+        Xt[(long long)(8 * k + j) * xq + gq] =
+            make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
+      }
+    }
+  } else if ((P & 3) == 0) {
+    // NCHW rows are 8-byte aligned: a piece is two 8-byte loads; four pieces in flight per thread
+    for (int i0 = t; i0 < ncw * pg; i0 += 4 * T) {
+      uint2 lo[4], hi[4];
+      int cs[4], gs[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = min(i0 + u * T, ncw * pg - 1);
+        cs[u] = fdivi(i, pg);
+        gs[u] = i - cs[u] * pg;
+        const uint16_t* src = xb + (long long)(cb0 + cs[u]) * P + 8 * gs[u];
+        lo[u] = *(const uint2*)src;
+        hi[u] = 8 * gs[u] + 4 < P ? *(const uint2*)(src + 4) : make_uint2(0, 0);  // (P % 4 == 0: a whole half or none)
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (i0 + u * T < ncw * pg) Xt[(long long)cs[u] * xq + gs[u]] = make_uint4(lo[u].x, lo[u].y, hi[u].x, hi[u].y);
+    }
+  } else {
+    for (int i = t; i < ncw * pg; i += T) {
+      const int c = fdivi(i, pg), gq = i - c * pg;  // pixel group fastest
+      uint32_t v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int pp = min(8 * gq + u, P - 1);
+        const uint16_t e = xb[(long long)(cb0 + c) * P + pp];
+        v[u] = 8 * gq + u < P ? e : 0;
+      }
+      Xt[(long long)c * xq + gq] = make_uint4(v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16));
+    }
+  }
+  for (int i = t; i < ncw * (xq - pg); i += T) {  // the rest of every row (alignment + padding) reads as zero
+    const int c = fdivi(i, xq - pg), k = i - c * (xq - pg);
+    Xt[(long long)c * xq + pg + k] = make_uint4(0, 0, 0, 0);
+  }
+
+  const int nct = ncw >> 5;
+  for (int i0 = 0; i0 < nt; i0 += 2) {
+    const int nrt = min(2, nt - i0);
+    __syncthreads();  // Xt staged / previous Wd consumed
+    // ---- Wd for row tiles i0, i0 + 1: zero, then scatter the window slots of each row -----------------------
+    for (int i = t; i < nrt * 2 * 32 * wq; i += T) Wd[i] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    for (int i = t; i < nrt * 32 * K2; i += T) {
+      const int ri = fdivi(i, 32 * K2), rem = i - ri * 32 * K2, row = fdivi(rem, K2), j = rem - row * K2;
+      const int rr = 32 * (i0 + ri) + row;
+      if (rr < P) {
+        const int py = fdivi(rr, g.W), px = rr - py * g.W;
+        const int dy = j / K - R, dx = j % K - R;
+        if (py + dy >= 0 && py + dy < g.H && px + dx >= 0 && px + dx < g.W) {
+          const int ts = max(0, (32 * (i0 + ri) - band) & ~15);
+          const int tt = rr + dy * g.W + dx - ts;   // 0 <= tt < 16 * KW
+          const float w = Wt[rr * K2 + j];
+          const uint32_t hi = __float_as_uint(w) & 0xFFFF0000u;
+          const uint32_t lo = __float_as_uint(w - __uint_as_float(hi)) >> 16;
+          uint16_t* base = (uint16_t*)(Wd + (long long)(ri * 2 * 32 + row) * wq);
+          base[tt] = (uint16_t)(hi >> 16);
+          base[(long long)32 * wq * 8 + tt] = (uint16_t)lo;   // the lo image: 32 rows of wq pieces (8 bf16 each) further
+        }
+      }
+    }
+    __syncthreads();
+    // ---- output tiles (row tile, channel tile), one wavefront each -----------------------------------------------
+    for (int ot = wave; ot < nrt * nct; ot += nw) {
+      const int ri = fdivi(ot, nct), ct = ot - ri * nct;
+      const int it = i0 + ri, ts = max(0, (32 * it - band) & ~15);
+      const int ks = min(KW, (P - ts + 15) >> 4);   // steps whose pixels exist
+      const uint4* Wh = Wd + (long long)(ri * 2 * 32 + r) * wq + h;
+      const uint4* Wl = Wh + 32 * wq;
+      const uint4* Xr = Xt + (long long)(32 * ct + r) * xq + (ts >> 3) + h;
+      f32x16 acc;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+      // Orientation: the accumulator holds 4 CONSECUTIVE rows per register group, so the output index that is
+      // contiguous in memory goes on the rows and leaves as one 8-byte store per group: channels for
+      // channels-last (A = Xt), pixels for NCHW (A = Wd; needs P % 4 == 0 for the alignment, otherwise pixels
+      // stay on the lanes and leave as 2-byte stores).
+      const bool rows_are_channels = NHWC || (P & 3) != 0;
+      for (int s = 0; s < ks; ++s) {
+        const bf16x8 wh = __builtin_bit_cast(bf16x8, Wh[2 * s]), wl = __builtin_bit_cast(bf16x8, Wl[2 * s]);
+        const bf16x8 xv = __builtin_bit_cast(bf16x8, Xr[2 * s]);
+        if (rows_are_channels) {
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xv, wl, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xv, wh, acc, 0, 0, 0);
+        } else {
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, xv, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xv, acc, 0, 0, 0);
+        }
+      }
+      if (NHWC) {            // D[row = channel][col = pixel]: 4 consecutive channels of pixel r per group
+        const int pp = 32 * it + r;
+        if (pp < P) {
+#pragma unroll
+          for (int gq = 0; gq < 4; ++gq) {
+            uint2 w;
+            w.x = (uint32_t)f32_to_bf16(acc[4 * gq]) | ((uint32_t)f32_to_bf16(acc[4 * gq + 1]) << 16);
+            w.y = (uint32_t)f32_to_bf16(acc[4 * gq + 2]) | ((uint32_t)f32_to_bf16(acc[4 * gq + 3]) << 16);
+            *(uint2*)(gxb + (long long)pp * C + cb0 + 32 * ct + 8 * gq + 4 * h) = w;
+          }
+        }
+      } else if ((P & 3) == 0) {  // D[row = pixel][col = channel]: 4 consecutive pixels of channel r per group
+        uint16_t* dst = gxb + (long long)(cb0 + 32 * ct + r) * P + 32 * it + 4 * h;
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          if (32 * it + 8 * gq + 4 * h < P) {  // (P % 4 == 0: a whole group or none)
+            uint2 w;
+            w.x = (uint32_t)f32_to_bf16(acc[4 * gq]) | ((uint32_t)f32_to_bf16(acc[4 * gq + 1]) << 16);
+            w.y = (uint32_t)f32_to_bf16(acc[4 * gq + 2]) | ((uint32_t)f32_to_bf16(acc[4 * gq + 3]) << 16);
+            *(uint2*)(dst + 8 * gq) = w;
+          }
+        }
+      } else {               // D[row = channel][col = pixel], NCHW with odd rows: lanes along pixels, 2-byte stores
+        const int pp = 32 * it + r;
+        if (pp < P) {
+#pragma unroll
+          for (int e = 0; e < 16; ++e)
+            gxb[(long long)(cb0 + 32 * ct + (e & 3) + 8 * (e >> 2) + 4 * h) * P + pp] = f32_to_bf16(acc[e]);
+        }
+      }
+    }
+  }
+}
+
 // ---- backward -------------------------------------------------------------------------------
 // POOL: grad_out is not a map but the gradients of the two pooled outputs: go[b,n,p] = gnfpm[b,n]/P
 // for every p, and every grad_x[b,c,p] also receives ggap[b,c]/P (adjoint of the two means).
-template <int R, int M, bool BF, bool NHWC, bool POOL = false>
+template <int R, int M, bool BF, bool NHWC, bool POOL = false, bool GEMM = false>
 __global__ void __launch_bounds__(kBwdThreads) bwd_fast(const KP g, const void* __restrict__ x,
                                                         const void* __restrict__ go, const void* __restrict__ out,
                                                         const float* __restrict__ saved, void* __restrict__ gx,
                                                         const float* __restrict__ ggap,
                                                         const float* __restrict__ gnfpm) {
   static_assert(!POOL || (!BF && !NHWC), "fused pooling tail: NCHW float32 only");
+  static_assert(!GEMM || (BF && !POOL), "matrix-core phase B: bf16 storage only");
   constexpr int K = Win<R>::K, K2 = Win<R>::K2, N = Win<R>::N;
   extern __shared__ __attribute__((aligned(16))) float4 lds4[];
   const int P = g.P;
@@ -602,7 +778,7 @@ __global__ void __launch_bounds__(kBwdThreads) bwd_fast(const KP g, const void* 
 #if NFP_ABLATE & 64
   __builtin_memset(&st, 0, sizeof(st));
 #else
-  stage_issue<BF, NHWC>(st, xb, g, cb0, min(g.Cc, cb1 - cb0) >> 2, t, T, p, gl, active);
+  if constexpr (!GEMM) stage_issue<BF, NHWC>(st, xb, g, cb0, min(g.Cc, cb1 - cb0) >> 2, t, T, p, gl, active);
 #endif
   // nothing that consumes a loaded value may be scheduled above this line (hipcc otherwise hoists
   // e.g. rcp(|x_p|) into the load sequence and stalls the remaining loads behind a vmcnt wait)
@@ -737,6 +913,12 @@ __global__ void __launch_bounds__(kBwdThreads) bwd_fast(const KP g, const void* 
     }
     __syncthreads();
     NFP_STAMP(4);
+  }
+  if constexpr (GEMM) {
+    // (the coefficient tables behind Wt are dead: their LDS becomes the GEMM's operand images)
+    bwd_gemm_phase<R, NHWC>(g, Wt, (uint4*)slab, (const uint16_t*)x + (long long)b * g.sB,
+                            (uint16_t*)gx + (long long)b * g.sB, cb0, cb1, t, T);
+    return;
   }
   float w[K2];
   int off[K2];

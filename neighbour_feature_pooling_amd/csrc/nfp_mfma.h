@@ -17,9 +17,6 @@
 
 namespace nfp {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
 constexpr int kGramLd = 33;  // row stride of a stored tile (floats): column reads by 32 lanes hit 32 banks
 
 // LDSX: the image is first copied into LDS (coalesced 16-byte pieces, rows padded by 16 bytes so that the 32
@@ -76,7 +73,6 @@ __global__ void __launch_bounds__(512) fwd_gram(const KP g, const void* __restri
     f32x16 acc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-#pragma unroll 4
     for (int kk = 0; kk < (C >> 4); ++kk) {  // 16 channels per step = two 16-byte pieces per pixel row
       const uint4 av = A[2 * kk], bv = B[2 * kk];
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), acc,

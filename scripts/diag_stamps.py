@@ -26,13 +26,20 @@ ctor = dict(R=R, measure=meas, padding=R)
 if meas == "norm":
     ctor["p"] = 2
 m = NFPPooling(C, **ctor)
-x = torch.randn(B, C, S, S, device=dev, requires_grad=True)
-go = torch.randn(B, m.out_channels, S, S, device=dev)
+DT = torch.bfloat16 if os.environ.get("DIAG_BF16") == "1" else torch.float32
+x = torch.randn(B, C, S, S, device=dev).to(DT)
+if os.environ.get("DIAG_NHWC") == "1":
+    x = x.contiguous(memory_format=torch.channels_last)
+x.requires_grad_(True)
+go = torch.randn(B, m.out_channels, S, S, device=dev).to(DT)
 buf = torch.zeros(8192 * 16 * 2, dtype=torch.int64, device=dev)
 assert L.nfp_debug_set_stamp_buffer(buf.data_ptr()) == 0
 
 
 def report(name, nwg, nst):
+    if nwg == 0:
+        print(f"{name}: no stamps in this kernel")
+        return
     a = buf.cpu().numpy().reshape(-1, 16, 2)[:nwg, :max(nst, 7)]
     clk, wall = a[..., 0].astype(np.float64), a[..., 1].astype(np.float64)
     clk_all = clk; clk, wall = clk[:, :nst], wall[:, :nst]

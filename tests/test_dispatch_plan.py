@@ -56,12 +56,14 @@ def test_plan_does_not_launch_or_disturb_last_variant(lib):
 @pytest.mark.parametrize("d_kw,fwd,bwd", [
     (dict(shape=(64, 512, 7, 7)), "fwd_fast<R1,cos,f32,nchw>", "bwd_fast<R1,cos,f32,nchw>"),           # headline
     (dict(shape=(256, 192, 14, 14), R=2, measure="norm", dtype=_abi.BF16), "fwd_gram<R2,l2,bf16,nchw>",
-     "bwd_fast<R2,l2,bf16,nchw>"),                                                                      # config 5
+     "bwd_fast<R2,l2,bf16,nchw,mfma>"),                                                                 # config 5
     (dict(shape=(256, 200, 14, 14), R=2, measure="norm", dtype=_abi.BF16), "fwd_fast<R2,l2,bf16,nchw>",
      "bwd_fast<R2,l2,bf16,nchw>"),                                                                      # C % 16 != 0
     (dict(shape=(8, 512, 7, 7), channels_last=True), "fwd_fast<R1,cos,f32,nhwc>", "bwd_fast<R1,cos,f32,nhwc>"),
     (dict(shape=(256, 192, 14, 14), R=2, measure="norm", dtype=_abi.BF16, channels_last=True),
-     "fwd_gram<R2,l2,bf16,nhwc>", "bwd_fast<R2,l2,bf16,nhwc>"),                                         # ViT tokens: matrix cores
+     "fwd_gram<R2,l2,bf16,nhwc>", "bwd_fast<R2,l2,bf16,nhwc,mfma>"),                                    # ViT tokens: matrix cores
+    (dict(shape=(256, 512, 7, 7), dtype=_abi.BF16), "fwd_gram<R1,cos,bf16,nchw>", "bwd_fast<R1,cos,bf16,nchw>"),   # odd rows, no channel split
+    (dict(shape=(64, 512, 7, 7), dtype=_abi.BF16), "fwd_gram<R1,cos,bf16,nchw>", "bwd_fast<R1,cos,bf16,nchw,mfma>"),
     (dict(shape=(64, 512, 7, 7), measure="norm", p=1.0), "fwd_pairs", "bwd_gather"),                    # reference default p
     (dict(shape=(64, 512, 7, 7), pad=0), "fwd_pairs", "bwd_gather"),                                    # pad != R
     (dict(shape=(64, 512, 7, 7), stride=2), "fwd_pairs", "bwd_gather"),

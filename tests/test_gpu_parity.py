@@ -720,10 +720,22 @@ def test_matrix_core_forward_bf16(B, C, H, W, R, meas, mode, kind, dev, monkeypa
     assert rel_err(out.detach().float().cpu().numpy(), ref.float().cpu().numpy()) <= 1e-2
     if kind == "const":
         assert out[:, :, 1:-1, 1:-1].abs().max().item() == 0.0 if R == 1 else True
-    # the backward (vector kernel) consumes what this forward saved
+    # the backward: phase B on the matrix cores too (when C % 32 == 0), against the vector kernel and float64
     monkeypatch.setenv("NFP_MFMA", "1")
     go = torch.randn(out.shape, generator=g).to(dev).bfloat16()
-    gx, = torch.autograd.grad(m(x), x, go)
+    o1 = m(x)
+    gx, = torch.autograd.grad(o1, x, go, retain_graph=True)
+    bv = _abi.load().nfp_last_variant().decode()
+    if C % 32 == 0 and bv.startswith("bwd_fast") and not (kind == "nchw" and (H * W) % 4 and B > 128):
+        assert bv.endswith(",mfma>"), bv          # (maps whose phase-A tables exceed LDS go to the general kernels)
+        gx2, = torch.autograd.grad(o1, x, go, retain_graph=True)
+        assert torch.equal(gx, gx2)                                  # deterministic
+        monkeypatch.setenv("NFP_MFMA", "0")
+        gv, = torch.autograd.grad(o1, x, go)
+        assert not _abi.load().nfp_last_variant().decode().endswith(",mfma>")
+        monkeypatch.setenv("NFP_MFMA", "1")
+        if kind not in ("const", "smooth"):
+            assert (gx.float() - gv.float()).abs().max().item() <= 2 ** -6 * gv.float().abs().max().item()
     x64 = x.detach().double().requires_grad_(True)
     gref, = torch.autograd.grad(nfp_host(x64, m.config), x64, go.double())
     if kind not in ("const", "smooth"):                               # (those have |out| ~ 0: sqrt'(0))
