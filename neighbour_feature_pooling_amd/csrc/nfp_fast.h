@@ -858,19 +858,27 @@ __global__ void __launch_bounds__(kBwdThreads) bwd_fast(const KP g, const void* 
     float* Osq = Out + P * K2;  // [P][K2]
     float* SPs = Osq + P * K2;  // [P]
     if (active && !(NFP_ABLATE & 16)) {
+      // the pixel's own rows of the pair tables, read ONCE into registers: left inside the slot loop they are
+      // re-read for every slot (hipcc cannot hoist them past the Out / Osq stores) and this phase becomes
+      // LDS-bandwidth bound — 18 ds_read_b128 per (pixel, slot), 11 k cycles per workgroup at k = 5
+      int4 qr[N / 4];
+      float4 cr4[N / 4], sr4[N / 4];
+#pragma unroll
+      for (int m = 0; m < N / 4; ++m) {
+        qr[m] = ((const int4*)(Qt + p * N))[m];
+        cr4[m] = ((const float4*)(CR + p * N))[m];
+        sr4[m] = ((const float4*)(SQ + p * N))[m];
+      }
       for (int j = gl; j < K2; j += g.G) {
         const int jy = j / K, jx = j - jy * K;
         const int ty = py + jy - R, tx = px + jx - R;
         const bool inside = ty >= 0 && ty < g.H && tx >= 0 && tx < g.W;
         const int tt = inside ? ty * g.W + tx : -2;
-        const int4* qa = (const int4*)(Qt + p * N);
-        const float4* ca = (const float4*)(CR + p * N);
-        const float4* sa = (const float4*)(SQ + p * N);
         float o = 0.f, q2 = 0.f;
 #pragma unroll
         for (int m = 0; m < N / 4; ++m) {
-          const int4 qq = qa[m];
-          const float4 cc = ca[m], ss = sa[m];
+          const int4 qq = qr[m];
+          const float4 cc = cr4[m], ss = sr4[m];
           o += (qq.x == tt ? cc.x : 0.f) + (qq.y == tt ? cc.y : 0.f) + (qq.z == tt ? cc.z : 0.f) +
                (qq.w == tt ? cc.w : 0.f);
           q2 += (qq.x == tt ? ss.x : 0.f) + (qq.y == tt ? ss.y : 0.f) + (qq.z == tt ? ss.z : 0.f) +
