@@ -1,20 +1,23 @@
-// nfp_gather.h — any-geometry, any-measure backward in GATHER form (no atomics, bitwise deterministic).
+// nfp_gather.h — the kernels for EVERY measure and EVERY nn.Conv2d geometry (bitwise deterministic, no atomics):
+//   fwd_pairs           forward, one workgroup per (image, tile of outputs)      [second half of this file]
+//   bwd_gather          backward in gather form, one workgroup per (image, channel block)
+//   bwd_gather_banded   the same per band of grad_x rows, for maps whose whole-image tables exceed LDS
+// Shared: the LDS slab float4[channel quad][pixel + 1] (the extra pixel is the zero a zero-padded tap reads) and
+// its staging from any strides / f32 / bf16 (stage_quads).
 //
-// Replaces, for every measure of nfp.py:141-342 and every nn.Conv2d geometry, the autograd graph of
-// measure -> view -> frozen depthwise conv -> pad (nfp.py:132-159).  grad_x[c][r] is the sum of
+// Backward.  It replaces the autograd graph of measure -> view -> frozen depthwise conv -> pad
+// (nfp.py:132-159).  grad_x[c][r] is the sum of
 //   * "centre role":    for every output o whose centre tap lands on r, and each of its N neighbours:
 //                       d out[n,o] / d a   with a = x[c][r],  b = x[c][q(o,n)]
 //   * "neighbour role": for every (o, n) whose neighbour tap lands on r:
 //                       d out[n,o] / d b   with a = x[c][centre(o)],  b = x[c][r]
-// The adjoint of pad / stride / dilation is an inverse index map.  It depends on the geometry only and
-// is separable, so each workgroup inverts it analytically into one short reader list per ROW and per
-// COLUMN in LDS (H + W threads, a few dozen integer steps each); the readers of pixel (ry, rx) are the
-// product of the two lists, walked in a fixed order.  Next to them sits a table of the per-pair backward
-// scalars Meas<M>::coef (grad_out, saved output and saved per-pixel stats enter only here).  The channel loop then reads x from an LDS slab laid out
-// float4[channel quad][pixel] and accumulates grad_x in registers: one ds_read_b128 serves four
-// pair-gradients, nothing is scattered, and grad_x is stored straight from registers.
-// The LDS-atomic kernel (nfp_generic.h::bwd_generic) stays as the fallback for maps whose tables do not
-// fit in LDS.
+// The adjoint of pad / stride / dilation is an inverse index map.  It depends on the geometry only and is
+// separable, so each workgroup inverts it analytically into one short reader list per ROW and per COLUMN in LDS;
+// the readers of pixel (ry, rx) are the product of the two lists, walked in a fixed order.  Next to them sits a
+// table of the per-pair backward scalars Meas<M>::coef (grad_out, saved output and saved per-pixel stats enter only
+// here).  Thread (pixel, 16 channels) then accumulates grad_x in registers — one ds_read_b128 serves four
+// pair-gradients, nothing is scattered — and stores it directly.  The LDS-atomic kernel
+// (nfp_generic.h::bwd_generic) stays as the last resort (circular / over-padded maps beyond the LDS tables).
 #pragma once
 #include "nfp_measures.h"
 
