@@ -563,13 +563,14 @@ int launch_fwd_gram(const KP& g, const void* x, void* out, float* saved, hipStre
   const size_t image = (size_t)g.P * (g.C / 8 + 1) * 16;
   if (tiles > (size_t)kLdsMax) return kNotApplicable;
   if (g.contig && tiles + image > (size_t)kLdsMax) return kNotApplicable;  // NCHW is transposed through LDS only
+  if (tiles + (size_t)g.P * 8 > (size_t)kLdsMax) return kNotApplicable;  // (the norm tables reuse the image's words)
   snprintf(g_variant, sizeof(g_variant), "fwd_gram<R%d,%s,bf16,%s>", R, M == NFP_COSINE ? "cos" : "l2",
            g.contig ? "nchw" : "nhwc");
   if (g.contig)
-    return launch("fwd_gram", fwd_gram<R, M, true, true>, dim3(g.B), dim3(512), tiles + image, st, g, x, out, saved, D);
+    return launch("fwd_gram", fwd_gram<R, M, true, true>, dim3(g.B), dim3(1024), tiles + image, st, g, x, out, saved, D);
   if (tiles + image <= (size_t)kLdsMax)
-    return launch("fwd_gram", fwd_gram<R, M, true>, dim3(g.B), dim3(512), tiles + image, st, g, x, out, saved, D);
-  return launch("fwd_gram", fwd_gram<R, M, false>, dim3(g.B), dim3(512), tiles, st, g, x, out, saved, D);
+    return launch("fwd_gram", fwd_gram<R, M, true>, dim3(g.B), dim3(1024), tiles + image, st, g, x, out, saved, D);
+  return launch("fwd_gram", fwd_gram<R, M, false>, dim3(g.B), dim3(1024), tiles + (size_t)g.P * 8, st, g, x, out, saved, D);
 }
 
 // Phase B of the backward on the matrix cores (nfp_fast.h::bwd_gemm_phase): bf16 storage, C a multiple of 32.

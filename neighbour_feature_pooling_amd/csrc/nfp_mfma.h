@@ -27,7 +27,7 @@ constexpr int kGramLd = 33;  // row stride of a stored tile (floats): column rea
 // NCHW: bf16 NCHW input, transposed into the same LDS image (thread = (pixel, 8 channels): eight 2-byte loads,
 // coalesced along the pixel axis, packed into one 16-byte LDS write); needs LDSX.
 template <int R, int M, bool LDSX, bool NCHW = false>
-__global__ void __launch_bounds__(512) fwd_gram(const KP g, const void* __restrict__ x, void* __restrict__ out,
+__global__ void __launch_bounds__(1024) fwd_gram(const KP g, const void* __restrict__ x, void* __restrict__ out,
                                                 float* __restrict__ saved, int D) {
   constexpr int K = 2 * R + 1, N = K * K - 1;
   extern __shared__ __attribute__((aligned(16))) float Gt[];  // [nt * (D + 1)][32][kGramLd], then the image
@@ -85,8 +85,8 @@ __global__ void __launch_bounds__(512) fwd_gram(const KP g, const void* __restri
   __syncthreads();
 
   // ---- outputs: thread (p, n = gl, gl + G, ...), as fwd_fast ------------------------------------------------------
-  const int G = max(1, T / P), gl = fdivi(t, P), p = t - gl * P;
-  if (gl >= G) return;
+  const int G = max(1, T / P), gl = fdivi(t, P), pr = t - gl * P;
+  const int p = gl < G ? pr : 0;  // (surplus threads idle through the barrier below)
   auto gram = [&](int a, int c) -> float {  // G[a][c] for pixels within the band
     const int ta = a >> 5, tc = c >> 5;
     const int lo = min(ta, tc), dd = abs(ta - tc);
@@ -97,16 +97,25 @@ __global__ void __launch_bounds__(512) fwd_gram(const KP g, const void* __restri
   NbrMap<R> nm;
   nm.init(g, py, px);
   void* ob = (char*)out + (long long)b * N * P * 2;
-  const float n2p = gram(p, p);
-  const float ip = inv_norm(n2p, g.inv_eps);
+  // per-pixel |x|^2 (and 1/max(|x|, eps) for cosine) once, in the LDS words behind the image / tiles' diagonal use
+  float* n2t = (float*)xl;  // the image is dead: every tile is finished (barrier above)
+  if (gl == 0 && t < P) {
+    const float d = gram(p, p);
+    n2t[p] = d;
+    if (M == NFP_COSINE) n2t[P + p] = inv_norm(d, g.inv_eps);
+  }
+  __syncthreads();
+  if (gl >= G) return;
+  const float n2p = n2t[p];
+  const float ip = M == NFP_COSINE ? n2t[P + p] : 0.f;
   for (int n = gl; n < N; n += G) {
     int qy, qx;
     const int q = nm.get(g, n, qy, qx);
     const int qc = max(q, 0);
-    const float n2q = gram(qc, qc), dot = gram(p, qc);
+    const float n2q = n2t[qc], dot = gram(p, qc);
     float v;
     if (M == NFP_COSINE) {
-      const float s = q < 0 ? 0.f : dot * ip * inv_norm(n2q, g.inv_eps);
+      const float s = q < 0 ? 0.f : dot * ip * n2t[P + qc];
       v = g.similarity ? s : 1.f - s;
     } else {
       float d2;
