@@ -675,7 +675,7 @@ __device__ __forceinline__ void bwd_gemm_phase(const KP& g, const float* Wt, uin
 // POOL: grad_out is not a map but the gradients of the two pooled outputs: go[b,n,p] = gnfpm[b,n]/P
 // for every p, and every grad_x[b,c,p] also receives ggap[b,c]/P (adjoint of the two means).
 template <int R, int M, bool BF, bool NHWC, bool POOL = false, bool GEMM = false>
-__global__ void __launch_bounds__(kBwdThreads) bwd_fast(const KP g, const void* __restrict__ x,
+__global__ void __launch_bounds__(GEMM ? 1024 : kBwdThreads) bwd_fast(const KP g, const void* __restrict__ x,
                                                         const void* __restrict__ go, const void* __restrict__ out,
                                                         const float* __restrict__ saved, void* __restrict__ gx,
                                                         const float* __restrict__ ggap,

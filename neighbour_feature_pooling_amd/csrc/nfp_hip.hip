@@ -587,7 +587,9 @@ int launch_bwd_gemm_t(KP g, const void* x, const void* go, const void* out, cons
   // NCHW rows that are not 8-byte aligned (H*W % 4 != 0) are staged and stored 2 bytes at a time: that only pays
   // while the batch is small enough for the channel split (measured: 7.2 vs 8.4 us at B = 64, 16.1 vs 14.0 at 256)
   if (!NHWC && (g.P & 3) && S < 2) return kNotApplicable;
-  g.G = kBwdThreads / g.P;
+  // the matrix-core variant keeps nothing of x in registers, so it may run 16 wavefronts: that pays when phase A has
+  // thousands of table entries to build (k = 5 at 14x14: 36 -> 29.5 us), not at 7x7 with k = 3 (7.2 -> 7.7 us)
+  g.G = (g.P * K2 > 2048 ? 1024 : kBwdThreads) / g.P;
   if (g.G < 1) g.G = 1;
   if (g.G > g.Cwg / 4) g.G = g.Cwg / 4;
   const int T = ((g.P * g.G + 63) / 64) * 64;
