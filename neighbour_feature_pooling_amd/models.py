@@ -185,6 +185,8 @@ class NFPNet(nn.Module):
             tok = feats[:, 1:]
             B, N, C = tok.shape
             H = W = int(math.isqrt(N))
-            feats = tok.transpose(1, 2).reshape(B, C, H, W)
+            # a VIEW with channels-last strides (the reference's reshape copies into NCHW): the NFP kernels read the
+            # token matrix in place, and [pixel][channel] is exactly the matrix-core forward's fragment layout
+            feats = tok.transpose(1, 2).unflatten(2, (H, W))
         x = self.pool(feats)
         return self.fc(x.view(x.size(0), -1))
