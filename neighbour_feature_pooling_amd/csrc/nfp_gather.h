@@ -297,8 +297,11 @@ __device__ __forceinline__ void gather_item(const KP& g, const float4* const (&s
   }
 }
 
+#ifndef NFP_GATHER_T
+#define NFP_GATHER_T 512
+#endif
 template <int M, int QB>
-__global__ void __launch_bounds__(512) bwd_gather(const KP g, const GatherLds L, const void* __restrict__ x,
+__global__ void __launch_bounds__(NFP_GATHER_T) bwd_gather(const KP g, const GatherLds L, const void* __restrict__ x,
                                                   const void* __restrict__ go, const void* __restrict__ out,
                                                   const float* __restrict__ saved, void* __restrict__ gx) {
   extern __shared__ __attribute__((aligned(16))) float lds[];

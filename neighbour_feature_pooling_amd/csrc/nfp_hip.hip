@@ -295,7 +295,7 @@ int launch_bwd_gather(const KP& g, const void* x, const void* go, const void* ou
   w = (w + 3) & ~3LL;
   if (w * 4 > kLdsMax) return kNotApplicable;
   L.xs = (int)w;
-  L.Ts = 128;  // of 512 threads
+  L.Ts = NFP_GATHER_T / 4;  // a quarter of the threads stage
   const size_t table_bytes = (size_t)w * 4, quad_bytes = (size_t)(g.P + 1) * 16;
   if (table_bytes + QB * quad_bytes > (size_t)kLdsMax) return kNotApplicable;
   const int Q = (g.C + 3) / 4;
@@ -315,7 +315,7 @@ int launch_bwd_gather(const KP& g, const void* x, const void* go, const void* ou
   L.Cq = Cq;
   const size_t lds = table_bytes + (size_t)Cq * quad_bytes;
   snprintf(g_variant, sizeof(g_variant), "bwd_gather");
-  return launch("bwd_gather", bwd_gather<M, QB>, dim3(g.B, S), dim3(512), lds, st, g, L, x, go, out, saved, gx);
+  return launch("bwd_gather", bwd_gather<M, QB>, dim3(g.B, S), dim3(NFP_GATHER_T), lds, st, g, L, x, go, out, saved, gx);
 }
 
 // Banded variant for maps whose whole-image tables exceed LDS (nfp_gather.h::bwd_gather_banded).
