@@ -9,6 +9,10 @@
  * types.  All tensor pointers are DEVICE pointers; the caller owns every
  * buffer (the library never allocates, frees or retains one), kernels are
  * enqueued on the caller's hipStream_t and nothing synchronises the device.
+ * Re-entrant: calls from several threads (autograd runs the backward on its own
+ * thread) share only a launch counter and the lock-protected "last variant"
+ * string; the error string, the dispatcher's scratch and nfp_plan's output are
+ * per calling thread.  No entry point reads the environment.
  *
  * Return value of every int function: 0 = ok, <0 = NFP_E_* below (message in
  * nfp_last_error(), thread-local).  Nothing throws or aborts.
@@ -23,7 +27,7 @@
 extern "C" {
 #endif
 
-#define NFP_ABI_VERSION 3
+#define NFP_ABI_VERSION 4
 
 /* error codes */
 #define NFP_OK 0
@@ -78,7 +82,11 @@ typedef struct nfp_desc {
   float p;                   /* nfp.py:30 — ord of Norm, exponent of SCS                */
   float eps;                 /* nfp.py:33                                               */
   float q_scs;               /* nfp.py:34                                               */
-  int64_t sxB, sxC, sxH, sxW; /* element strides of x (and of grad_x)                   */
+  int64_t sxB, sxC, sxH, sxW; /* element strides of x; grad_x shares sxC / sxH / sxW    */
+  int64_t sgB;               /* batch stride of grad_x in elements, 0 = sxB.  A view whose
+                                images are dense but spaced apart (ViT tokens behind a class
+                                token, texture_pooling.py:181-188) is read in place and still
+                                gets a dense gradient                                       */
 } nfp_desc;
 
 int nfp_abi_version(void);
@@ -96,7 +104,8 @@ int64_t nfp_saved_floats(const nfp_desc* d);
 /* NFPPooling.forward (nfp.py:132-134) for the measure in d.
  *   x      [B,C,H,W] by strides, dtype d->dtype
  *   out    [B,N,Ho,Wo] contiguous, dtype d->dtype
- *   saved  float[nfp_saved_floats(d)] or NULL when no backward will follow */
+ *   saved  float[nfp_saved_floats(d)] or NULL when no backward will follow
+ *          (Attention on bf16 maps always needs it: the raw dots live there) */
 int nfp_forward(const nfp_desc* d, const void* x, void* out, float* saved, void* hip_stream);
 
 /* The autograd backward of the same call: grad_x = d(sum(out*grad_out))/dx.
@@ -124,9 +133,15 @@ int nfp_pool_backward(const nfp_desc* d, const void* x, const float* grad_gap, c
  * the HIP path, not a fallback, produced a result). */
 uint64_t nfp_launch_count(void);
 
-/* Name of the kernel variant the last nfp_forward / nfp_backward of this
- * process selected (for bench / profile bookkeeping). */
+/* Name of the kernel variant the last successful nfp_forward / nfp_backward /
+ * nfp_pool_* of this PROCESS selected (for bench / profile bookkeeping),
+ * copied into a buffer of the calling thread. */
 const char* nfp_last_variant(void);
+
+/* Test hook: re-read the NFP_* A/B switches (NFP_FORCE_GENERIC, NFP_FWD_SCALAR,
+ * NFP_BWD_ATOMIC, NFP_BWD_BANDS, NFP_MFMA) from the environment.  They are
+ * otherwise read once, when the library is loaded. */
+void nfp_reload_env(void);
 
 /* Describe, WITHOUT touching the GPU, what nfp_forward (backward = 0) or
  * nfp_backward (backward != 0) would launch for `d` with 4 KiB-aligned buffers:

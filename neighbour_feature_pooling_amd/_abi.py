@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libnfp_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 MEASURES = ["norm", "cosine", "dot", "rmse", "geman", "attention", "emd", "canberra", "hellinger",
             "chisquared1", "chisquared2", "gfc", "pearson", "jeffrey", "squaredchord", "smith", "scs"]
@@ -19,7 +19,7 @@ F32, BF16 = 0, 1
 
 EXPORTS = ["nfp_abi_version", "nfp_last_error", "nfp_output_shape", "nfp_saved_floats", "nfp_forward",
            "nfp_backward", "nfp_pool_supported", "nfp_pool_forward", "nfp_pool_backward", "nfp_launch_count",
-           "nfp_last_variant", "nfp_plan"]
+           "nfp_last_variant", "nfp_plan", "nfp_reload_env"]
 
 
 class NfpDesc(ctypes.Structure):
@@ -28,7 +28,7 @@ class NfpDesc(ctypes.Structure):
                 ("B", "C", "H", "W", "R", "pad", "stride", "dilation", "pad_mode", "measure",
                  "similarity", "diff_weights", "dtype")] + \
                [("p", ctypes.c_float), ("eps", ctypes.c_float), ("q_scs", ctypes.c_float)] + \
-               [(n, ctypes.c_int64) for n in ("sxB", "sxC", "sxH", "sxW")]
+               [(n, ctypes.c_int64) for n in ("sxB", "sxC", "sxH", "sxW", "sgB")]
 
 
 class NfpError(RuntimeError):
@@ -58,6 +58,7 @@ def load():
     L.nfp_last_error.restype = ctypes.c_char_p
     L.nfp_last_variant.restype = ctypes.c_char_p
     L.nfp_launch_count.restype = ctypes.c_uint64
+    L.nfp_reload_env.restype = None
     L.nfp_plan.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_char_p, ctypes.c_int32]
     L.nfp_plan.restype = ctypes.c_int
     L.nfp_output_shape.argtypes = [dp, i32p, i32p, i32p]

@@ -20,8 +20,10 @@ struct KP {
   int Ho, Wo, O;  // O = Ho*Wo outputs per neighbour map
   int measure, similarity, diff, dtype;
   int godtype;  // dtype of the grad_out the backward kernel reads (f32 scratch for Attention)
+  int odtype;   // dtype the general forward kernels store `out` in (f32 scratch for Attention's raw dots)
   float p, eps, q_scs;
-  long long sB, sC, sH, sW;  // element strides of x / grad_x
+  long long sB, sC, sH, sW;  // element strides of x; grad_x shares sC / sH / sW
+  long long gB;              // batch stride of grad_x (a batch-strided view of x gets a dense gradient)
   int contig;                // x is NCHW-contiguous
   // launch shape
   int Cc;   // channels per LDS chunk
@@ -76,21 +78,10 @@ __device__ __forceinline__ int nbr_pixel(const KP& g, int o, int n) {
   return tap_pixel(g, o, t / g.k, t - (t / g.k) * g.k);
 }
 
-// Diagnostic build only (-DNFP_STAMPS, scripts/diag_stamps.py): thread 0 of every workgroup records
-// {shader clock, 100 MHz wall clock} at phase boundaries into a buffer nothing else reads.
+// In-kernel phase stamps exist only in the diagnostic build (-DNFP_STAMPS, scripts/diag_stamps.py includes
+// nfp_diag.h); in the product build the two macros expand to nothing.
 #ifdef NFP_STAMPS
-__device__ unsigned long long* nfp_stamp_buf = nullptr;
-// The buffer pointer is read ONCE (a vector load + wait at kernel entry); a stamp is then one
-// s_memtime/s_memrealtime pair and two stores, with no vmcnt wait, so loads in flight stay in flight.
-#define NFP_STAMP_INIT() unsigned long long* nfp_sb_ = nfp_stamp_buf
-#define NFP_STAMP(id)                                                                        \
-  do {                                                                                       \
-    if (threadIdx.x == 0 && nfp_sb_) {                                                       \
-      unsigned long long wg = blockIdx.x + (unsigned long long)gridDim.x * blockIdx.y;       \
-      nfp_sb_[(wg * 16 + (id)) * 2] = __builtin_amdgcn_s_memtime();                         \
-      nfp_sb_[(wg * 16 + (id)) * 2 + 1] = __builtin_amdgcn_s_memrealtime();                 \
-    }                                                                                        \
-  } while (0)
+#include "nfp_diag.h"
 #else
 #define NFP_STAMP_INIT() do { } while (0)
 #define NFP_STAMP(id) do { } while (0)

@@ -27,10 +27,6 @@
 #pragma once
 #include "nfp_measures.h"
 
-#ifndef NFP_ABLATE
-#define NFP_ABLATE 0  // diagnostic builds only (scripts/diag_ablate.py): bit mask of phases to skip
-#endif
-
 namespace nfp {
 
 // tuning knobs (A/B tested with scripts/ab_flags.py; the defaults are the measured best)
@@ -318,11 +314,7 @@ __global__ void __launch_bounds__(MAXT) fwd_fast(const KP g, const void* __restr
   NFP_STAMP(0);
   NFP_STAMP(6);
   Staged<NHWC> st;
-#if NFP_ABLATE & 4
-  __builtin_memset(&st, 0, sizeof(st));
-#else
   stage_issue<BF, NHWC>(st, xb, g, 0, min(g.Cc, g.C) >> 2, t, T, p, gl, active);
-#endif
   __builtin_amdgcn_sched_barrier(0);
   NFP_STAMP(1);
 
@@ -375,16 +367,11 @@ __global__ void __launch_bounds__(MAXT) fwd_fast(const KP g, const void* __restr
     int done = 0;
 #pragma unroll
     for (int part = 0; part < kRB; ++part) {
-#if NFP_ABLATE & 2
-      const int upto = part + 1 >= kRB ? ncq : min(ncq, ((part + 1) * T) / (g.P >> 2));
-      if constexpr (!NHWC) asm volatile("" ::"v"(st.blk[0][0].x), "v"(st.blk[kRB - 1][3].w), "v"(st.tl[0].x));
-#else
       const int upto = stage_commit<BF, NHWC>(st, slab, g, ncq, t, T, p, gl, active, part);
-#endif
       if (upto == done) continue;  // uniform: nothing new became complete
       __syncthreads();
       if (part == 0) NFP_STAMP(2);
-      if (active && !(NFP_ABLATE & 1)) {
+      if (active) {
         // this thread's quads gl, gl+G, ... inside [done, upto)
         int cq = gl + ((max(done - gl, 0) + g.G - 1) / g.G) * g.G;
 #pragma unroll NFP_UNROLL_F
@@ -422,10 +409,6 @@ __global__ void __launch_bounds__(MAXT) fwd_fast(const KP g, const void* __restr
       }
     }
   }
-#if NFP_ABLATE & 8
-  if (active) stx(out, ((long long)b * N) * P + p + gl * P, acc[0] + acc[NF - 1] + nrm, NFP_F32);
-  return;
-#endif
   // channel-group reduction through LDS, fixed order
   __syncthreads();
   NFP_STAMP(3);
@@ -701,7 +684,7 @@ __global__ void __launch_bounds__(GEMM ? 1024 : kBwdThreads) bwd_fast(const KP g
   constexpr int DT = BF ? NFP_BF16 : NFP_F32;
   constexpr int ES = BF ? 2 : 4;
   const Rsrc xb = make_rsrc((const char*)x + (long long)b * g.sB * ES, (long long)g.C * P * ES);  // wave-uniform
-  const Rsrc gxb = make_rsrc((char*)gx + (long long)b * g.sB * ES, (long long)g.C * P * ES);
+  const Rsrc gxb = make_rsrc((char*)gx + (long long)b * g.gB * ES, (long long)g.C * P * ES);
   const void* gob = (const char*)go + (long long)b * N * P * ES;
   const void* outb = (const char*)out + (long long)b * N * P * ES;
 
@@ -770,32 +753,24 @@ __global__ void __launch_bounds__(GEMM ? 1024 : kBwdThreads) bwd_fast(const KP g
       }
     }
   };
-#if !(NFP_ABLATE & 16)
   a1_load(gl);
-#endif
   __builtin_amdgcn_sched_barrier(0);  // keep these (small, needed first) loads ahead of the x chunk
   Staged<NHWC> st;
-#if NFP_ABLATE & 64
-  __builtin_memset(&st, 0, sizeof(st));
-#else
   if constexpr (!GEMM) stage_issue<BF, NHWC>(st, xb, g, cb0, min(g.Cc, cb1 - cb0) >> 2, t, T, p, gl, active);
-#endif
   // nothing that consumes a loaded value may be scheduled above this line (hipcc otherwise hoists
   // e.g. rcp(|x_p|) into the load sequence and stalls the remaining loads behind a vmcnt wait)
   __builtin_amdgcn_sched_barrier(0);
   NFP_STAMP(1);
-#if !(NFP_ABLATE & 16)
   a1_math(gl);
   for (int n0 = gl + 4 * g.G; n0 < N; n0 += 4 * g.G) {
     a1_load(n0);
     a1_math(n0);
   }
-#endif
   __syncthreads();
   NFP_STAMP(2);
   if constexpr (R == 1) {
     // A2: gather.  Thread (r = p, slot j = gl, gl+G, ...), t = r + delta_j if inside the image.
-    if (active && !(NFP_ABLATE & 16)) {
+    if (active) {
       for (int j = gl; j < K2; j += g.G) {
         const int jy = j / K, jx = j - jy * K;
         const int ty = py + jy - R, tx = px + jx - R;
@@ -840,7 +815,7 @@ __global__ void __launch_bounds__(GEMM ? 1024 : kBwdThreads) bwd_fast(const KP g
     __syncthreads();
     NFP_STAMP(3);
     // A3: fold the neighbour-role self terms into the diagonal, fixed order
-    if (gl == 0 && !(NFP_ABLATE & 16)) {
+    if (gl == 0) {
       float s = Wt[p * K2 + K2 / 2];
   #pragma unroll
       for (int j = 0; j < K2; ++j) s += Sq2[p * K2 + j];
@@ -857,7 +832,7 @@ __global__ void __launch_bounds__(GEMM ? 1024 : kBwdThreads) bwd_fast(const KP g
     float* Out = Sq2 + P * K2;  // [P][K2]
     float* Osq = Out + P * K2;  // [P][K2]
     float* SPs = Osq + P * K2;  // [P]
-    if (active && !(NFP_ABLATE & 16)) {
+    if (active) {
       // the pixel's own rows of the pair tables, read ONCE into registers: left inside the slot loop they are
       // re-read for every slot (hipcc cannot hoist them past the Out / Osq stores) and this phase becomes
       // LDS-bandwidth bound — 18 ds_read_b128 per (pixel, slot), 11 k cycles per workgroup at k = 5
@@ -900,7 +875,7 @@ __global__ void __launch_bounds__(GEMM ? 1024 : kBwdThreads) bwd_fast(const KP g
     }
     __syncthreads();
     NFP_STAMP(3);
-    if (active && !(NFP_ABLATE & 16)) {
+    if (active) {
       for (int j = gl; j < K2; j += g.G) {
         const int jy = j / K, jx = j - jy * K;
         const int ty = py + jy - R, tx = px + jx - R;
@@ -925,7 +900,7 @@ __global__ void __launch_bounds__(GEMM ? 1024 : kBwdThreads) bwd_fast(const KP g
   if constexpr (GEMM) {
     // (the coefficient tables behind Wt are dead: their LDS becomes the GEMM's operand images)
     bwd_gemm_phase<R, NHWC>(g, Wt, (uint4*)slab, (const uint16_t*)x + (long long)b * g.sB,
-                            (uint16_t*)gx + (long long)b * g.sB, cb0, cb1, t, T);
+                            (uint16_t*)gx + (long long)b * g.gB, cb0, cb1, t, T);
     return;
   }
   float w[K2];
@@ -935,7 +910,7 @@ __global__ void __launch_bounds__(GEMM ? 1024 : kBwdThreads) bwd_fast(const KP g
     const int dy = j / K - R, dx = j % K - R;
     const bool ok = py + dy >= 0 && py + dy < g.H && px + dx >= 0 && px + dx < g.W;
     off[j] = ok ? swz(p + dy * g.W + dx) - swz(p) : 0;
-    w[j] = (NFP_ABLATE & 16) ? 0.1f * j : (ok ? Wt[p * K2 + j] : 0.f);
+    w[j] = ok ? Wt[p * K2 + j] : 0.f;
   }
   // B: one pass over the channel block; results leave straight from registers with write-through
   // (sc1) stores — 4 dwords per slot for NCHW, one 16-byte store for channels-last — so grad_x
@@ -948,13 +923,11 @@ __global__ void __launch_bounds__(GEMM ? 1024 : kBwdThreads) bwd_fast(const KP g
       __syncthreads();
       stage_issue<BF, NHWC>(st, xb, g, c0, ncq, t, T, p, gl, active);
     }
-#if !(NFP_ABLATE & 64)
 #pragma unroll
     for (int part = 0; part < kRB; ++part) stage_commit<BF, NHWC>(st, slab, g, ncq, t, T, p, gl, active, part);
-#endif
     __syncthreads();
     NFP_STAMP(5);
-    if (active && !(NFP_ABLATE & 32)) {
+    if (active) {
 #pragma unroll NFP_UNROLL_B
       for (int cq = gl; cq < ncq; cq += g.G) {
         const float4* row = slab + cq * Pp + sp;
@@ -971,9 +944,6 @@ __global__ void __launch_bounds__(GEMM ? 1024 : kBwdThreads) bwd_fast(const KP g
           r4.z = fmaf(w[j], q.z, r4.z);
           r4.w = fmaf(w[j], q.w, r4.w);
         }
-#if NFP_ABLATE & 128
-        asm volatile("" ::"v"(r4.x), "v"(r4.y), "v"(r4.z), "v"(r4.w));
-#else
         if constexpr (NHWC) {
           store_px4<BF>(gxb, p * g.C + c0 + 4 * cq, 0, r4);
         } else {
@@ -983,7 +953,6 @@ __global__ void __launch_bounds__(GEMM ? 1024 : kBwdThreads) bwd_fast(const KP g
           store_1<BF>(gxb, e, 2 * P, r4.z);
           store_1<BF>(gxb, e, 3 * P, r4.w);
         }
-#endif
       }
     }
   }

@@ -416,7 +416,7 @@ __global__ void __launch_bounds__(NFP_GATHER_T) bwd_gather(const KP g, const Gat
         const int cq = qb * QB + u;
         if (cq < cqn) {
           const int c = 4 * (qc0 + cq);
-          const long long base = (long long)b * g.sB + (long long)c * g.sC + (long long)ry * g.sH + (long long)rx * g.sW;
+          const long long base = (long long)b * g.gB + (long long)c * g.sC + (long long)ry * g.sH + (long long)rx * g.sW;
           stx(gx, base, acc[u].x, g.dtype);
           if (c + 1 < g.C) stx(gx, base + g.sC, acc[u].y, g.dtype);
           if (c + 2 < g.C) stx(gx, base + 2 * g.sC, acc[u].z, g.dtype);
@@ -533,7 +533,7 @@ __global__ void __launch_bounds__(512) bwd_gather_banded(const KP g, const BandL
     for (int i = t; i < (qe - qa) * 4 * nr * g.W; i += T) {
       const int c = 4 * qa + i / (nr * g.W), rl = i % (nr * g.W);
       if (c < g.C)
-        stx(gx, (long long)b * g.sB + (long long)c * g.sC + (long long)(ra + rl / g.W) * g.sH +
+        stx(gx, (long long)b * g.gB + (long long)c * g.sC + (long long)(ra + rl / g.W) * g.sH +
                 (long long)(rl % g.W) * g.sW, __builtin_nanf(""), g.dtype);
     }
     return;
@@ -620,7 +620,7 @@ __global__ void __launch_bounds__(512) bwd_gather_banded(const KP g, const BandL
         const int cq = qb * QB + u;
         if (cq < cqn) {
           const int c = 4 * (qc0 + cq);
-          const long long base = (long long)b * g.sB + (long long)c * g.sC + (long long)ry * g.sH + (long long)rx * g.sW;
+          const long long base = (long long)b * g.gB + (long long)c * g.sC + (long long)ry * g.sH + (long long)rx * g.sW;
           stx(gx, base, acc[u].x, g.dtype);
           if (c + 1 < g.C) stx(gx, base + g.sC, acc[u].y, g.dtype);
           if (c + 2 < g.C) stx(gx, base + 2 * g.sC, acc[u].z, g.dtype);
@@ -802,7 +802,7 @@ __global__ void __launch_bounds__(512) fwd_pairs(const KP g, const PairsLds L, c
         for (int p2 = 0; p2 < parts; ++p2) v += red[(p2 * NN + cg) * L.Ot + ol];
         const int qz = tap[n * L.Ot + ol];
         stx(out, ((long long)b * g.N + n) * g.O + o0 + ol,
-            Meas<M>::fin(v, st[pcz], st[PS + pcz], st[qz], st[PS + qz], g), g.dtype);
+            Meas<M>::fin(v, st[pcz], st[PS + pcz], st[qz], st[PS + qz], g), g.odtype);
       }
     } else if (ol < on) {
       for (int j = cg; j < NNv; j += rows) {
@@ -811,7 +811,7 @@ __global__ void __launch_bounds__(512) fwd_pairs(const KP g, const PairsLds L, c
         for (int c2 = 0; c2 < L.G; ++c2) s += red[(c2 * NN + j) * L.Ot + ol];
         const int qz = tap[n * L.Ot + ol];
         stx(out, ((long long)b * g.N + n) * g.O + o0 + ol,
-            Meas<M>::fin(s, st[pcz], st[PS + pcz], st[qz], st[PS + qz], g), g.dtype);
+            Meas<M>::fin(s, st[pcz], st[PS + pcz], st[qz], st[PS + qz], g), g.odtype);
       }
     }
   }

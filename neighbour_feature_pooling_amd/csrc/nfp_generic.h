@@ -79,7 +79,7 @@ __device__ __forceinline__ void stage_chunk(float* xs, const void* x, const KP& 
 __device__ __forceinline__ void unstage_chunk(const float* gs, void* gx, const KP& g, int b, int c0, int cc) {
   const int t = threadIdx.x, T = blockDim.x, n = cc * g.P;
   if (g.contig) {
-    const long long base = (long long)b * g.sB + (long long)c0 * g.P;
+    const long long base = (long long)b * g.gB + (long long)c0 * g.P;
     if (g.dtype == NFP_F32) {
       float* dst = (float*)gx + base;
       if ((((uintptr_t)dst) & 15) == 0) {
@@ -111,13 +111,13 @@ __device__ __forceinline__ void unstage_chunk(const float* gs, void* gx, const K
     for (int i = t; i < n; i += T) {
       int pix = i / cc, c = i - pix * cc;
       int y = pix / g.W, xx = pix - y * g.W;
-      stx(gx, (long long)b * g.sB + (long long)y * g.sH + (long long)xx * g.sW + c0 + c, gs[c * g.P + pix], g.dtype);
+      stx(gx, (long long)b * g.gB + (long long)y * g.sH + (long long)xx * g.sW + c0 + c, gs[c * g.P + pix], g.dtype);
     }
   } else {
     for (int i = t; i < n; i += T) {
       int c = i / g.P, pix = i - c * g.P;
       int y = pix / g.W, xx = pix - y * g.W;
-      stx(gx, (long long)b * g.sB + (long long)(c0 + c) * g.sC + (long long)y * g.sH + (long long)xx * g.sW, gs[i],
+      stx(gx, (long long)b * g.gB + (long long)(c0 + c) * g.sC + (long long)y * g.sH + (long long)xx * g.sW, gs[i],
           g.dtype);
     }
   }
@@ -200,7 +200,7 @@ __global__ void __launch_bounds__(1024) fwd_generic(const KP g, const void* __re
       int n = grp * kGroup + j;
       if (n < g.N) {
         float v = Meas<M>::fin(acc[j], sa0, sa1, sb0[j], sb1[j], g);
-        stx(out, ((long long)b * g.N + n) * g.O + o, v, g.dtype);
+        stx(out, ((long long)b * g.N + n) * g.O + o, v, g.odtype);
       }
     }
     if constexpr (Meas<M>::NSTAT > 0) if (saved != nullptr) {
@@ -288,19 +288,21 @@ __global__ void __launch_bounds__(1024) bwd_generic(const KP g, const void* __re
   }
 }
 
-// ---- Attention (nfp.py:195-205): softmax over the N neighbour maps, in place on out[b, :, o] ------
-__global__ void __launch_bounds__(256) attn_softmax_fwd(const KP g, void* __restrict__ out) {
+// ---- Attention (nfp.py:195-205): softmax over the N neighbour maps of the raw dots `src` (f32: in place on out
+// for float32 maps, the scratch of nfp_saved_floats for bf16 maps, so that the dots are rounded to bf16 never and
+// the probabilities once) ------
+__global__ void __launch_bounds__(256) attn_softmax_fwd(const KP g, const float* src, void* out) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // (b, o)
   if (i >= (long long)g.B * g.O) return;
   const long long b = i / g.O, o = i - b * g.O;
   const long long base = b * g.N * g.O + o;
   float mx = -INFINITY;
-  for (int n = 0; n < g.N; ++n) mx = fmaxf(mx, ldx(out, base + (long long)n * g.O, g.dtype));
+  for (int n = 0; n < g.N; ++n) mx = fmaxf(mx, src[base + (long long)n * g.O]);
   float s = 0.f;
-  for (int n = 0; n < g.N; ++n) s += expf(ldx(out, base + (long long)n * g.O, g.dtype) - mx);
+  for (int n = 0; n < g.N; ++n) s += expf(src[base + (long long)n * g.O] - mx);
   const float sg = g.similarity ? 1.f : -1.f;
   for (int n = 0; n < g.N; ++n) {
-    float y = expf(ldx(out, base + (long long)n * g.O, g.dtype) - mx) / s;
+    float y = expf(src[base + (long long)n * g.O] - mx) / s;
     stx(out, base + (long long)n * g.O, sg * y, g.dtype);
   }
 }

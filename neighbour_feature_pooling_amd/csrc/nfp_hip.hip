@@ -25,8 +25,44 @@ using namespace nfp;
 namespace {
 
 thread_local char g_err[512] = "";
-char g_variant[64] = "";  // process-wide: backward runs on an autograd worker thread
+// The dispatcher names the variant it picked in a buffer of the CALLING thread (forward and autograd's backward
+// thread dispatch concurrently); a finished nfp_forward / nfp_backward publishes it under a lock as the process's
+// "last variant", which nfp_last_variant() copies back into the reader's own thread.
+thread_local char g_variant[64] = "";
+thread_local char t_variant_out[64] = "";
+std::mutex g_variant_mu;
+char g_variant_last[64] = "";
 std::atomic<uint64_t> g_launches{0};
+
+void publish_variant() {
+  std::lock_guard<std::mutex> lock(g_variant_mu);
+  memcpy(g_variant_last, g_variant, sizeof(g_variant_last));
+}
+
+// Test / A-B switches, read from the environment ONCE when the library is loaded (and again only when a test
+// calls nfp_reload_env): the launch path itself never calls getenv.
+struct Switches {
+  std::atomic<int> fwd_scalar{0}, bwd_atomic{0}, bwd_bands{0}, force_generic{0}, mfma{1};
+};
+Switches g_sw;
+#ifndef NFP_MFMA_DEFAULT
+#define NFP_MFMA_DEFAULT 1
+#endif
+void read_env() {
+  auto flag = [](const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? (e[0] == '1' ? 1 : 0) : dflt;
+  };
+  g_sw.fwd_scalar = flag("NFP_FWD_SCALAR", 0);
+  g_sw.bwd_atomic = flag("NFP_BWD_ATOMIC", 0);
+  g_sw.force_generic = flag("NFP_FORCE_GENERIC", 0);
+  g_sw.mfma = flag("NFP_MFMA", NFP_MFMA_DEFAULT);
+  const char* e = getenv("NFP_BWD_BANDS");
+  g_sw.bwd_bands = e ? atoi(e) : 0;
+}
+struct EnvInit {
+  EnvInit() { read_env(); }
+} g_env_init;
 
 int fail(int code, const char* fmt, ...) {
   va_list ap;
@@ -82,8 +118,10 @@ int make_kp(const nfp_desc* d, KP* g) {
   g->O = g->Ho * g->Wo;
   g->measure = d->measure; g->similarity = d->similarity != 0; g->diff = d->diff_weights != 0; g->dtype = d->dtype;
   g->godtype = d->dtype;
+  g->odtype = d->dtype;
   g->p = d->p; g->eps = d->eps; g->q_scs = d->q_scs;
   g->sB = d->sxB; g->sC = d->sxC; g->sH = d->sxH; g->sW = d->sxW;
+  g->gB = d->sgB != 0 ? d->sgB : d->sxB;
   g->contig = (d->sxW == 1 && d->sxH == d->W && d->sxC == (int64_t)d->H * d->W) ? 1 : 0;
   g->invP = 1.0f / (float)g->P;
   g->invW = 1.0f / (float)g->W;
@@ -109,10 +147,13 @@ int stats_of(int measure) {
 template <typename K>
 int set_lds(K kernel, size_t bytes) {
   if (bytes <= 64 * 1024) return NFP_OK;
+  // hipFuncSetAttribute applies to the kernel ON THE CURRENT DEVICE: remembered per (device, kernel)
   static std::mutex mu;
-  static std::unordered_map<const void*, size_t> granted;
+  static std::unordered_map<uintptr_t, size_t> granted;
+  int dev = 0;
+  if (int rc = hip_ok(hipGetDevice(&dev), "hipGetDevice")) return rc;
   std::lock_guard<std::mutex> lock(mu);
-  size_t& have = granted[(const void*)kernel];
+  size_t& have = granted[(uintptr_t)(const void*)kernel * 64 + (uintptr_t)(dev & 63)];
   if (have >= bytes) return NFP_OK;
   if (int rc = hip_ok(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMax),
                       "hipFuncSetAttribute(max dynamic LDS)"))
@@ -148,10 +189,7 @@ int launch(const char* name, K kernel, dim3 grid, dim3 block, size_t lds, hipStr
 // ---- generic launches -----------------------------------------------------------------------
 // Forward of nfp_gather.h (fwd_pairs): one workgroup per (image, tile of outputs); declines only when not even
 // one channel quad of the map fits next to its tables, then the chunked scalar kernel below serves the call.
-bool force_scalar_fwd() {
-  const char* e = getenv("NFP_FWD_SCALAR");
-  return e && e[0] == '1';
-}
+bool force_scalar_fwd() { return g_sw.fwd_scalar.load(std::memory_order_relaxed) != 0; }
 
 template <int M, int NN>
 int launch_fwd_pairs_t(const KP& g, const void* x, void* out, float* saved, hipStream_t st) {
@@ -245,14 +283,9 @@ int launch_fwd_generic(KP g, const void* x, void* out, float* saved, hipStream_t
 
 // Gather-form backward (nfp_gather.h): tables + one slab of >= QB channel quads must fit in LDS and the
 // packed 16-bit indices must hold; otherwise the LDS-atomic kernel below serves the call.
-bool force_atomic() {
-  const char* e = getenv("NFP_BWD_ATOMIC");
-  return e && e[0] == '1';
-}
-int force_bands() {  // tests: NFP_BWD_BANDS=n sends every call through the banded kernel with >= n bands
-  const char* e = getenv("NFP_BWD_BANDS");
-  return e ? atoi(e) : 0;
-}
+bool force_atomic() { return g_sw.bwd_atomic.load(std::memory_order_relaxed) != 0; }
+// tests: NFP_BWD_BANDS=n sends every call through the banded kernel with >= n bands
+int force_bands() { return g_sw.bwd_bands.load(std::memory_order_relaxed); }
 
 #ifndef NFP_GATHER_WGS
 #define NFP_GATHER_WGS 512
@@ -426,10 +459,7 @@ int launch_bwd_generic(KP g, const void* x, const void* go, const void* out, con
 constexpr int kSlabBudgetFwd = NFP_FWD_SLAB_KB * 1024;
 constexpr int kSlabBudgetBwd = NFP_BWD_SLAB_KB * 1024;
 
-bool force_generic() {
-  const char* e = getenv("NFP_FORCE_GENERIC");
-  return e && e[0] == '1';
-}
+bool force_generic() { return g_sw.force_generic.load(std::memory_order_relaxed) != 0; }
 
 // Which calls the hot-path kernels serve; everything else runs on the generic kernels.
 bool fast_ok(const KP& g, const void* x, const void* gx) {
@@ -442,7 +472,8 @@ bool fast_ok(const KP& g, const void* x, const void* gx) {
   if (!g.contig && !nhwc) return false;
   if (!g.contig) {  // vector loads of 4 channels need natural alignment
     const uintptr_t m = g.dtype == NFP_F32 ? 15 : 7;
-    if (((uintptr_t)x & m) || ((uintptr_t)gx & m) || ((g.sB * (g.dtype == NFP_F32 ? 4 : 2)) & m)) return false;
+    const int es = g.dtype == NFP_F32 ? 4 : 2;
+    if (((uintptr_t)x & m) || ((uintptr_t)gx & m) || ((g.sB * es) & m) || ((g.gB * es) & m)) return false;
   }
   return true;
 }
@@ -547,17 +578,12 @@ int launch_bwd_fast_t(KP g, const void* x, const void* go, const void* out, cons
 }
 
 // Matrix-core forward (nfp_mfma.h): bf16, dense channels-last, C a multiple of 16.
-#ifndef NFP_MFMA_DEFAULT
-#define NFP_MFMA_DEFAULT 1
-#endif
-bool mfma_enabled() {
-  const char* e = getenv("NFP_MFMA");
-  return e ? e[0] == '1' : NFP_MFMA_DEFAULT != 0;
-}
+bool mfma_enabled() { return g_sw.mfma.load(std::memory_order_relaxed) != 0; }
 
 template <int R, int M>
 int launch_fwd_gram(const KP& g, const void* x, void* out, float* saved, hipStream_t st) {
   if (!mfma_enabled() || g.dtype != NFP_BF16 || (g.C & 15) || g.P > 512) return kNotApplicable;
+  if (!g.contig && (((uintptr_t)x & 15) || ((g.sB * 2) & 15))) return kNotApplicable;  // 16-byte fragment loads
   const int nt = (g.P + 31) / 32, D = std::min(nt - 1, (g.R * g.W + g.R + 31) / 32);
   const size_t tiles = (((size_t)nt * (D + 1) * 32 * kGramLd + 3) & ~(size_t)3) * 4;
   const size_t image = (size_t)g.P * (g.C / 8 + 1) * 16;
@@ -579,6 +605,7 @@ int launch_bwd_gemm_t(KP g, const void* x, const void* go, const void* out, cons
                       hipStream_t st) {
   constexpr int N = Win<R>::N, K2 = Win<R>::K2;
   if (!mfma_enabled() || g.dtype != NFP_BF16 || (g.C & 31)) return kNotApplicable;
+  if (NHWC && (((uintptr_t)x & 15) || ((g.sB * 2) & 15))) return kNotApplicable;  // 16-byte staging loads
   int S = (NFP_BWD_WGS + g.B - 1) / g.B;  // channel blocks per image, whole 32-channel tiles each
   if (S > g.C / 32) S = g.C / 32;
   if (S < 1) S = 1;
@@ -635,7 +662,12 @@ extern "C" {
 
 int nfp_abi_version(void) { return NFP_ABI_VERSION; }
 const char* nfp_last_error(void) { return g_err; }
-const char* nfp_last_variant(void) { return g_variant; }
+const char* nfp_last_variant(void) {
+  std::lock_guard<std::mutex> lock(g_variant_mu);
+  memcpy(t_variant_out, g_variant_last, sizeof(t_variant_out));
+  return t_variant_out;
+}
+void nfp_reload_env(void) { read_env(); }
 uint64_t nfp_launch_count(void) { return g_launches.load(); }
 
 int nfp_output_shape(const nfp_desc* d, int32_t* N, int32_t* Ho, int32_t* Wo) {
@@ -654,7 +686,19 @@ int64_t nfp_saved_floats(const nfp_desc* d) {
   return (int64_t)stats_of(g.measure) * g.B * g.P;
 }
 
-int nfp_forward(const nfp_desc* d, const void* x, void* out, float* saved, void* hip_stream) {
+}  // extern "C"
+
+namespace {
+
+// What leaves the library is 0 or a negative NFP_E_* code: a launcher's internal "not applicable" can only mean
+// that no kernel serves the descriptor.
+int finish(int rc, const char* what) {
+  if (rc == kNotApplicable) return fail(NFP_E_UNSUPPORTED, "%s: no kernel serves this descriptor", what);
+  if (rc == NFP_OK && !t_dry) publish_variant();
+  return rc;
+}
+
+int forward_impl(const nfp_desc* d, const void* x, void* out, float* saved, void* hip_stream) {
   KP g;
   if (int rc = make_kp(d, &g)) return rc;
   if (!x || !out) return fail(NFP_E_INVALID, "null tensor pointer");
@@ -697,13 +741,18 @@ int nfp_forward(const nfp_desc* d, const void* x, void* out, float* saved, void*
     case NFP_SQUAREDCHORD: return launch_fwd_generic<NFP_SQUAREDCHORD>(g, x, out, saved, st);
     case NFP_SMITH: return launch_fwd_generic<NFP_SMITH>(g, x, out, saved, st);
     case NFP_ATTENTION: {
-      if (g.dtype != NFP_F32) return fail(NFP_E_UNSUPPORTED, "attention: float32 only");
+      // raw dots in f32: in `out` itself for float32 maps, in the caller's scratch (nfp_saved_floats) for bf16
+      if (g.dtype != NFP_F32 && !saved)
+        return fail(NFP_E_INVALID, "attention on bf16 maps needs the scratch of nfp_saved_floats (also without a backward)");
+      float* dots = g.dtype == NFP_F32 ? (float*)out : saved;
       KP gd = g;
       gd.similarity = 1;  // raw dots first; the sign belongs to the softmax output (nfp.py:203-204)
-      if (int rc = launch_fwd_generic<NFP_DOT>(gd, x, out, nullptr, st)) return rc;
+      gd.odtype = NFP_F32;
+      if (int rc = launch_fwd_generic<NFP_DOT>(gd, x, dots, nullptr, st)) return rc;
       const long long n = (long long)g.B * g.O;
       strncat(g_variant, "+attn_softmax", sizeof(g_variant) - strlen(g_variant) - 1);
-      return launch("attn_softmax_fwd", attn_softmax_fwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, g, out);
+      return launch("attn_softmax_fwd", attn_softmax_fwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, g,
+                    (const float*)dots, out);
     }
     default:
       return fail(NFP_E_UNSUPPORTED, "measure %d (SharpenedCosine mixes batch elements in the reference, "
@@ -711,8 +760,8 @@ int nfp_forward(const nfp_desc* d, const void* x, void* out, float* saved, void*
   }
 }
 
-int nfp_backward(const nfp_desc* d, const void* x, const void* grad_out, const void* out, const float* saved,
-                 void* grad_x, void* hip_stream) {
+int backward_impl(const nfp_desc* d, const void* x, const void* grad_out, const void* out, const float* saved,
+                  void* grad_x, void* hip_stream) {
   KP g;
   if (int rc = make_kp(d, &g)) return rc;
   if (!x || !grad_out || !out || !grad_x) return fail(NFP_E_INVALID, "null tensor pointer");
@@ -749,7 +798,6 @@ int nfp_backward(const nfp_desc* d, const void* x, const void* grad_out, const v
     case NFP_SQUAREDCHORD: return launch_bwd_generic<NFP_SQUAREDCHORD>(g, x, grad_out, out, saved, grad_x, st);
     case NFP_SMITH: return launch_bwd_generic<NFP_SMITH>(g, x, grad_out, out, saved, grad_x, st);
     case NFP_ATTENTION: {
-      if (g.dtype != NFP_F32) return fail(NFP_E_UNSUPPORTED, "attention: float32 only");
       float* gd = const_cast<float*>(saved);  // scratch handed over by nfp_forward's caller (nfp_saved_floats)
       const long long n = (long long)g.B * g.O;
       if (int rc = launch("attn_softmax_bwd", attn_softmax_bwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, g,
@@ -765,22 +813,33 @@ int nfp_backward(const nfp_desc* d, const void* x, const void* grad_out, const v
   }
 }
 
+}  // namespace
+
+extern "C" {
+
+int nfp_forward(const nfp_desc* d, const void* x, void* out, float* saved, void* hip_stream) {
+  return finish(forward_impl(d, x, out, saved, hip_stream), "nfp_forward");
+}
+
+int nfp_backward(const nfp_desc* d, const void* x, const void* grad_out, const void* out, const float* saved,
+                 void* grad_x, void* hip_stream) {
+  return finish(backward_impl(d, x, grad_out, out, saved, grad_x, hip_stream), "nfp_backward");
+}
+
 // What would nfp_forward / nfp_backward launch for this descriptor?  Nothing touches the GPU: the dispatcher runs
 // in plan mode with 4 KiB-aligned stand-in pointers and the launches are described into `buf` as
 //   "<variant> | <kernel> grid=(x,y,z) block=t lds=bytes[; <kernel> ...]".
 int nfp_plan(const nfp_desc* d, int32_t backward, char* buf, int32_t buflen) {
   if (!buf || buflen < 1) return fail(NFP_E_INVALID, "null plan buffer");
   buf[0] = 0;
-  char keep[sizeof(g_variant)];
-  memcpy(keep, g_variant, sizeof(keep));
-  t_dry = true;
+  t_dry = true;  // (thread-local, like the variant and plan buffers: concurrent calls do not see each other)
   t_plan[0] = 0;
   void* fake = (void*)(uintptr_t)0x1000;
-  const int rc = backward ? nfp_backward(d, fake, fake, fake, (const float*)fake, fake, nullptr)
-                          : nfp_forward(d, fake, fake, (float*)fake, nullptr);
+  const int rc = finish(backward ? backward_impl(d, fake, fake, fake, (const float*)fake, fake, nullptr)
+                                 : forward_impl(d, fake, fake, (float*)fake, nullptr),
+                        "nfp_plan");
   t_dry = false;
   if (rc == NFP_OK) snprintf(buf, (size_t)buflen, "%s | %s", g_variant, t_plan);
-  memcpy(g_variant, keep, sizeof(keep));
   return rc;
 }
 
@@ -803,11 +862,14 @@ int nfp_pool_forward(const nfp_desc* d, const void* x, float* gap, float* nfpm, 
   if (!nfp_pool_supported(d)) return fail(NFP_E_UNSUPPORTED, "fused pooling tail: hot-path geometry, NCHW float32 only");
   if (g.B == 0) return NFP_OK;
   hipStream_t st = (hipStream_t)hip_stream;
+  int rc;
   if (g.measure == NFP_COSINE)
-    return g.R == 1 ? launch_fwd_fast_t<1, NFP_COSINE, false, false, true>(g, x, out_map, saved, st, gap, nfpm)
-                    : launch_fwd_fast_t<2, NFP_COSINE, false, false, true>(g, x, out_map, saved, st, gap, nfpm);
-  return g.R == 1 ? launch_fwd_fast_t<1, NFP_NORM, false, false, true>(g, x, out_map, saved, st, gap, nfpm)
+    rc = g.R == 1 ? launch_fwd_fast_t<1, NFP_COSINE, false, false, true>(g, x, out_map, saved, st, gap, nfpm)
+                  : launch_fwd_fast_t<2, NFP_COSINE, false, false, true>(g, x, out_map, saved, st, gap, nfpm);
+  else
+    rc = g.R == 1 ? launch_fwd_fast_t<1, NFP_NORM, false, false, true>(g, x, out_map, saved, st, gap, nfpm)
                   : launch_fwd_fast_t<2, NFP_NORM, false, false, true>(g, x, out_map, saved, st, gap, nfpm);
+  return finish(rc, "nfp_pool_forward");
 }
 
 int nfp_pool_backward(const nfp_desc* d, const void* x, const float* grad_gap, const float* grad_nfpm,
@@ -819,11 +881,14 @@ int nfp_pool_backward(const nfp_desc* d, const void* x, const float* grad_gap, c
   if (stats_of(g.measure) > 0 && !saved) return fail(NFP_E_INVALID, "missing saved state");
   if (g.B == 0) return NFP_OK;
   hipStream_t st = (hipStream_t)hip_stream;
+  int rc;
   if (g.measure == NFP_COSINE)
-    return g.R == 1 ? launch_bwd_fast_t<1, NFP_COSINE, false, false, true>(g, x, nullptr, out_map, saved, grad_x, st, grad_gap, grad_nfpm)
-                    : launch_bwd_fast_t<2, NFP_COSINE, false, false, true>(g, x, nullptr, out_map, saved, grad_x, st, grad_gap, grad_nfpm);
-  return g.R == 1 ? launch_bwd_fast_t<1, NFP_NORM, false, false, true>(g, x, nullptr, out_map, saved, grad_x, st, grad_gap, grad_nfpm)
+    rc = g.R == 1 ? launch_bwd_fast_t<1, NFP_COSINE, false, false, true>(g, x, nullptr, out_map, saved, grad_x, st, grad_gap, grad_nfpm)
+                  : launch_bwd_fast_t<2, NFP_COSINE, false, false, true>(g, x, nullptr, out_map, saved, grad_x, st, grad_gap, grad_nfpm);
+  else
+    rc = g.R == 1 ? launch_bwd_fast_t<1, NFP_NORM, false, false, true>(g, x, nullptr, out_map, saved, grad_x, st, grad_gap, grad_nfpm)
                   : launch_bwd_fast_t<2, NFP_NORM, false, false, true>(g, x, nullptr, out_map, saved, grad_x, st, grad_gap, grad_nfpm);
+  return finish(rc, "nfp_pool_backward");
 }
 
 }  // extern "C"

@@ -6,6 +6,7 @@ pixel.  Nothing else can serve a CUDA tensor: if the library is missing or refus
 the configuration the call raises.  CPU tensors use `_host.nfp_host` (see there).
 """
 import ctypes
+from collections import OrderedDict
 from dataclasses import dataclass
 
 import torch
@@ -41,16 +42,44 @@ class NfpConfig:
 _DTYPES = {torch.float32: _abi.F32, torch.bfloat16: _abi.BF16}
 
 
+def _inner_layout(x):
+    """'nchw' / 'nhwc' when every image of x is dense in that order — whatever the batch stride: the kernels take the
+    batch stride from the descriptor, so e.g. ViT patch tokens behind a class token (a [B,1+HW,C] buffer viewed as
+    [B,C,H,W], texture_pooling.py:181-188) are read in place — else None."""
+    _, C, H, W = x.shape
+    st = x.stride()
+
+    def matches(canon):
+        return all(n == 1 or s == c for n, s, c in zip((C, H, W), st[1:], canon))
+
+    if matches((H * W, W, 1)):
+        return "nchw"
+    if matches((1, W * C, C)):
+        return "nhwc"
+    return None
+
+
+def _canonical_strides(x, layout):
+    """Element strides handed to the library (size-1 dimensions carry arbitrary strides in torch)."""
+    B, C, H, W = x.shape
+    sB = x.stride(0) if B > 1 else C * H * W
+    return (sB, H * W, W, 1) if layout == "nchw" else (sB, 1, W * C, C)
+
+
 def _dense(x):
-    """x as either NCHW-contiguous or channels-last-contiguous (read in place by strides)."""
-    if x.is_contiguous() or x.is_contiguous(memory_format=torch.channels_last):
-        return x
-    return x.contiguous()
+    """(x, layout): x itself when its images are dense NCHW or channels-last (read in place by strides), otherwise an
+    NCHW copy."""
+    layout = _inner_layout(x)
+    if layout is None or (x.shape[0] > 1 and x.stride(0) < x.shape[1] * x.shape[2] * x.shape[3]):
+        return x.contiguous(), "nchw"
+    return x, layout
 
 
-def make_desc(x, cfg):
+def make_desc(x, cfg, layout=None):
     if x.dtype not in _DTYPES:
         raise _abi.NfpUnsupported(f"NFP HIP kernels take float32 or bfloat16 feature maps, got {x.dtype}")
+    if layout is None:
+        x, layout = _dense(x)
     d = _abi.NfpDesc()
     d.B, d.C, d.H, d.W = x.shape
     d.R, d.pad, d.stride, d.dilation = cfg.R, cfg.padding, cfg.stride, cfg.dilation
@@ -60,7 +89,8 @@ def make_desc(x, cfg):
     d.diff_weights = int(bool(cfg.diff_weights))
     d.dtype = _DTYPES[x.dtype]
     d.p, d.eps, d.q_scs = float(cfg.p), float(cfg.eps), float(cfg.q_scs)
-    d.sxB, d.sxC, d.sxH, d.sxW = x.stride()
+    d.sxB, d.sxC, d.sxH, d.sxW = _canonical_strides(x, layout)
+    d.sgB = d.C * d.H * d.W          # grad_x is always allocated dense, in x's inner layout
     return d
 
 
@@ -71,21 +101,39 @@ def output_shape(d):
     return d.B, n.value, ho.value, wo.value
 
 
-_PLANS = {}
+_PLANS = OrderedDict()      # least recently used first
+_PLANS_MAX = 256
 
 
-def _plan(x, cfg):
-    """(descriptor, output shape, saved floats) for this input signature — cached: in eager mode the
-    host side of a call (a few ctypes round trips) otherwise costs more than the two kernels."""
-    key = (tuple(x.shape), x.stride(), x.dtype, cfg)
+def _plans_get(key):
     plan = _PLANS.get(key)
+    if plan is not None:
+        _PLANS.move_to_end(key)
+    return plan
+
+
+def _plans_put(key, plan):
+    _PLANS[key] = plan
+    if len(_PLANS) > _PLANS_MAX:
+        _PLANS.popitem(last=False)
+
+
+def _plan(x, layout, cfg):
+    """(descriptor, output shape, saved floats, why-no-backward) for this input signature — cached (LRU): in eager
+    mode the host side of a call (a few ctypes round trips) otherwise costs more than the two kernels.  The last
+    entry is None when nfp_backward serves the descriptor too, else the library's message: forward and backward
+    envelopes differ for a few large maps, and a call that will need a gradient must fail in forward(), not inside
+    loss.backward()."""
+    key = (tuple(x.shape), x.stride(0), layout, x.dtype, cfg)
+    plan = _plans_get(key)
     if plan is None:
         L = _abi.load()
-        d = make_desc(x, cfg)
-        plan = (d, output_shape(d), int(L.nfp_saved_floats(ctypes.byref(d))))
-        if len(_PLANS) > 256:
-            _PLANS.clear()
-        _PLANS[key] = plan
+        d = make_desc(x, cfg, layout)
+        buf = ctypes.create_string_buffer(1024)
+        rc = L.nfp_plan(ctypes.byref(d), 1, buf, len(buf))
+        no_bwd = None if rc == 0 else L.nfp_last_error().decode()
+        plan = (d, output_shape(d), int(L.nfp_saved_floats(ctypes.byref(d))), no_bwd)
+        _plans_put(key, plan)
     return plan
 
 
@@ -116,12 +164,18 @@ class _on_device:
 
 class _NfpHip(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, cfg):
+    def forward(ctx, x, cfg, need_grad):
+        # need_grad: x.requires_grad and grad mode on, sampled by the caller (grad mode is always off in here, and
+        # ctx.needs_input_grad ignores torch.no_grad())
         L = _abi.load()
-        x = _dense(x)
-        d, oshape, ns = _plan(x, cfg)
-        if not ctx.needs_input_grad[0]:
-            ns = 0
+        x, layout = _dense(x)
+        d, oshape, ns, no_bwd = _plan(x, layout, cfg)
+        if need_grad:
+            if no_bwd is not None:
+                raise _abi.NfpUnsupported(f"libnfp_hip: the forward of this call is served but its backward is not "
+                                          f"({no_bwd}); run it under torch.no_grad() or on a detached input")
+        elif not (cfg.measure == "attention" and x.dtype != torch.float32):
+            ns = 0      # (bf16 Attention keeps its raw dots in this scratch even without a backward)
         with _on_device(x.device):
             out = torch.empty(oshape, dtype=x.dtype, device=x.device)
             saved = torch.empty(max(ns, 0), dtype=torch.float32, device=x.device)
@@ -129,6 +183,7 @@ class _NfpHip(torch.autograd.Function):
             _abi.check(L.nfp_forward(ctypes.byref(d), x.data_ptr(), out.data_ptr(),
                                      saved.data_ptr() if ns > 0 else None, stream))
         ctx.desc = d
+        ctx.layout = layout
         ctx.save_for_backward(x, out, saved)
         return out
 
@@ -142,11 +197,13 @@ class _NfpHip(torch.autograd.Function):
         if go.dtype != x.dtype:
             go = go.to(x.dtype)
         with _on_device(x.device):
-            gx = torch.empty_like(x)  # same strides as x (dense NCHW or channels-last)
+            # dense, in x's inner layout (desc.sgB): a batch-strided view of x does not get a gradient with gaps
+            gx = torch.empty(x.shape, dtype=x.dtype, device=x.device,
+                             memory_format=torch.channels_last if ctx.layout == "nhwc" else torch.contiguous_format)
             stream = _raw_stream(x.device)
             _abi.check(L.nfp_backward(ctypes.byref(d), x.data_ptr(), go.data_ptr(), out.data_ptr(),
                                       saved.data_ptr() if saved.numel() else None, gx.data_ptr(), stream))
-        return gx, None
+        return gx, None, None
 
 
 class _NfpPoolHip(torch.autograd.Function):
@@ -156,7 +213,7 @@ class _NfpPoolHip(torch.autograd.Function):
     def forward(ctx, x, cfg):
         L = _abi.load()
         x = x.contiguous()
-        d, (B, N, Ho, Wo), ns = _plan(x, cfg)
+        d, (B, N, Ho, Wo), ns, _ = _plan(x, "nchw", cfg)
         with _on_device(x.device):
             gap = torch.empty(B, x.shape[1], dtype=torch.float32, device=x.device)
             nfpm = torch.empty(B, N, dtype=torch.float32, device=x.device)
@@ -190,9 +247,10 @@ def nfp_pool_fused_ok(x, cfg):
     if not (x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and x.is_contiguous()):
         return False
     key = ("pool", tuple(x.shape), cfg)
-    ok = _PLANS.get(key)
+    ok = _plans_get(key)
     if ok is None:
-        ok = _PLANS[key] = bool(_abi.load().nfp_pool_supported(ctypes.byref(make_desc(x, cfg))))
+        ok = bool(_abi.load().nfp_pool_supported(ctypes.byref(make_desc(x, cfg, "nchw"))))
+        _plans_put(key, ok)
     return ok
 
 
@@ -218,5 +276,5 @@ def nfp(x, cfg):
                       "PyTorch ops on the GPU, not through the HIP kernels", RuntimeWarning, stacklevel=3)
         return nfp_host(x, cfg)
     if x.is_cuda:
-        return _NfpHip.apply(x, cfg)
+        return _NfpHip.apply(x, cfg, x.requires_grad and torch.is_grad_enabled())
     return nfp_host(x, cfg)

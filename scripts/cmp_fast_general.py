@@ -21,6 +21,7 @@ for (B, C, S, R, meas, dt) in [(64, 512, 7, 1, "cosine", torch.float32), (64, 51
     row = {}
     for tag, env in (("fast", "0"), ("general", "1")):
         os.environ["NFP_FORCE_GENERIC"] = env
+        _abi.load().nfp_reload_env()
         with torch.cuda.stream(s):
             o = m(x)
             fv = L.nfp_last_variant().decode()
@@ -29,5 +30,6 @@ for (B, C, S, R, meas, dt) in [(64, 512, 7, 1, "cosine", torch.float32), (64, 51
             bv = L.nfp_last_variant().decode()
         row[tag] = (tf, tb, fv.split("<")[0], bv.split("<")[0])
     os.environ["NFP_FORCE_GENERIC"] = "0"
+    _abi.load().nfp_reload_env()
     print(f"[{B},{C},{S},{S}] k{2*R+1} {meas} {str(dt).split('.')[1]}: "
           + "  ".join(f"{k}: fwd {v[0]:6.2f} bwd {v[1]:6.2f} ({v[2]}/{v[3]})" for k, v in row.items()), flush=True)

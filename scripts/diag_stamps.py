@@ -10,10 +10,13 @@ import numpy as np
 import torch
 from neighbour_feature_pooling_amd import _abi, build
 
-diag = os.path.join(ROOT, "gpurun_out", "libnfp_hip_diag.so")
-os.makedirs(os.path.dirname(diag), exist_ok=True)
-subprocess.check_call([build.hipcc_path()] + build.HIPCC_FLAGS + ["-DNFP_STAMPS", "-o", diag,
-                      os.path.join(build.CSRC, "nfp_hip.hip")])
+# built in-tree (git-ignored *.so) so that a copy compiled in the CPU container travels to the GPU box
+diag = os.path.join(ROOT, "neighbour_feature_pooling_amd", "libnfp_hip_diag.so")
+if not os.path.exists(diag) or os.path.getmtime(diag) < build._newest_source_mtime():
+    subprocess.check_call([build.hipcc_path()] + build.HIPCC_FLAGS + ["-DNFP_STAMPS", "-o", diag,
+                          os.path.join(build.CSRC, "nfp_hip.hip")])
+if "--build-only" in sys.argv:
+    sys.exit(0)
 _abi.LIB_PATH = diag
 L = _abi.load()
 L.nfp_debug_set_stamp_buffer.argtypes = [ctypes.c_void_p]

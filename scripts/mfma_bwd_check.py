@@ -23,11 +23,13 @@ for (B, C, H, W, R, meas, mode, cl) in [(4, 192, 14, 14, 2, "norm", "reflect", T
         x = x.contiguous(memory_format=torch.channels_last)
     x.requires_grad_(True)
     os.environ["NFP_MFMA"] = "0"
+    _abi.load().nfp_reload_env()
     out = m(x)
     go = torch.randn_like(out)
     gv, = torch.autograd.grad(out, x, go, retain_graph=True)
     v0 = L.nfp_last_variant().decode()
     os.environ["NFP_MFMA"] = "1"
+    _abi.load().nfp_reload_env()
     gm, = torch.autograd.grad(out, x, go, retain_graph=True)
     v1 = L.nfp_last_variant().decode()
     assert "mfma" in v1 and "mfma" not in v0, (v0, v1)
@@ -51,6 +53,7 @@ for (B, C, S, R, meas, cl) in [(256, 192, 14, 2, "norm", True), (256, 192, 14, 2
     res = {}
     for env in ("1", "0"):
         os.environ["NFP_MFMA"] = env
+        _abi.load().nfp_reload_env()
         with torch.cuda.stream(s):
             out = m(x)
             tb = time_kernel_graph(lambda: torch.autograd.grad(out, x, go, retain_graph=True), 20, s)

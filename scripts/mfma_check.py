@@ -32,6 +32,7 @@ for (B, C, H, W, R, meas, mode, kind) in [(4, 192, 14, 14, 2, "norm", "reflect",
     outs = {}
     for env in ("1", "0"):
         os.environ["NFP_MFMA"] = env
+        _abi.load().nfp_reload_env()
         outs[env] = m(x).float()
         var = L.nfp_last_variant().decode()
         assert var.startswith("fwd_gram" if env == "1" else "fwd_fast"), var
@@ -57,6 +58,7 @@ for (B, C, S, R, meas, cl) in [(256, 192, 14, 2, "norm", True), (256, 192, 14, 2
     res = {}
     for env in ("1", "0"):
         os.environ["NFP_MFMA"] = env
+        _abi.load().nfp_reload_env()
         with torch.cuda.stream(s), torch.no_grad():
             m(x)
             res[env] = (time_kernel_graph(lambda: m(x), 20, s), L.nfp_last_variant().decode().split("<")[0])

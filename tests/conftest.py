@@ -37,3 +37,23 @@ def oracle_lib():
     import oracle
     oracle.build()
     return oracle
+
+
+@pytest.fixture(autouse=True)
+def _nfp_env_at_test_start():
+    """libnfp_hip.so reads its NFP_* A/B switches once; tests flip them with `nfp_switch`.  Start every test from
+    the environment as it is now (the previous test's monkeypatch has been undone by then)."""
+    from neighbour_feature_pooling_amd import _abi
+    if _abi._lib is not None:
+        _abi._lib.nfp_reload_env()
+    yield
+
+
+def nfp_switch(monkeypatch, name, value):
+    """Set (value=None: unset) one NFP_* switch for the rest of the test and make the library re-read them."""
+    from neighbour_feature_pooling_amd import _abi
+    if value is None:
+        monkeypatch.delenv(name, raising=False)
+    else:
+        monkeypatch.setenv(name, str(value))
+    _abi.load().nfp_reload_env()

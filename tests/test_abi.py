@@ -38,9 +38,10 @@ def test_abi_version_matches_header(lib):
 
 
 def test_desc_layout_matches_header():
-    # 13 int32 + 3 float + 4 int64, naturally aligned
-    assert ctypes.sizeof(_abi.NfpDesc) == 13 * 4 + 3 * 4 + 4 * 8
+    # 13 int32 + 3 float + 5 int64, naturally aligned
+    assert ctypes.sizeof(_abi.NfpDesc) == 13 * 4 + 3 * 4 + 5 * 8
     assert _abi.NfpDesc.sxB.offset == 64
+    assert _abi.NfpDesc.sgB.offset == 96
 
 
 def _desc(shape, R=1, pad=1, stride=1, dil=1, mode="reflect", measure="cosine"):
@@ -101,3 +102,63 @@ def test_invalid_descriptors_are_refused(lib):
 def test_saved_floats(lib):
     assert lib.nfp_saved_floats(ctypes.byref(_desc((64, 512, 7, 7)))) == 64 * 49
     assert lib.nfp_saved_floats(ctypes.byref(_desc((4, 192, 14, 14), R=2, pad=2, measure="norm"))) == 0
+
+
+def test_plan_is_reentrant_and_last_variant_is_stable(lib):
+    """include/nfp.h promises re-entrancy: two threads plan different descriptors in a loop while a third reads
+    nfp_last_variant; every plan must describe ITS descriptor and the published variant must never change (nfp_plan
+    publishes nothing) or be torn."""
+    import threading
+    before = lib.nfp_last_variant()
+    want = {"a": (_desc((64, 512, 7, 7)), b"fwd_fast<R1,cos,f32,nchw>"),
+            "b": (_desc((4, 192, 14, 14), R=2, pad=2, measure="norm"), b"fwd_fast<R2,l2,f32,nchw>")}
+    want["b"][0].diff_weights = 1
+    errors, stop = [], threading.Event()
+
+    def planner(key):
+        d, prefix = want[key]
+        buf = ctypes.create_string_buffer(1024)
+        for _ in range(3000):
+            rc = lib.nfp_plan(ctypes.byref(d), 0, buf, len(buf))
+            if rc != 0 or not buf.value.startswith(prefix):
+                errors.append((key, rc, buf.value))
+                return
+
+    def reader():
+        while not stop.is_set():
+            v = lib.nfp_last_variant()
+            if v != before:
+                errors.append(("reader", v))
+                return
+
+    ts = [threading.Thread(target=planner, args=(k,)) for k in want] + [threading.Thread(target=reader)]
+    for t in ts:
+        t.start()
+    for t in ts[:2]:
+        t.join()
+    stop.set()
+    ts[2].join()
+    assert not errors, errors[:3]
+
+
+def test_launch_path_never_reads_the_environment():
+    """The A/B switches are read when the library is loaded (and by nfp_reload_env), not per launch."""
+    src = open(os.path.join(ROOT, "neighbour_feature_pooling_amd", "csrc", "nfp_hip.hip")).read()
+    body = src[src.index("void read_env()"):]
+    body = body[body.index("\n}\n") + 3:]
+    assert "getenv" not in body
+    for header in os.listdir(os.path.join(ROOT, "neighbour_feature_pooling_amd", "csrc")):
+        if header.endswith(".h"):
+            assert "getenv" not in open(os.path.join(ROOT, "neighbour_feature_pooling_amd", "csrc", header)).read()
+
+
+def test_env_switches_take_effect_only_through_reload(lib, monkeypatch):
+    d = _desc((64, 512, 7, 7))
+    buf = ctypes.create_string_buffer(1024)
+    monkeypatch.setenv("NFP_FORCE_GENERIC", "1")
+    assert lib.nfp_plan(ctypes.byref(d), 0, buf, len(buf)) == 0 and buf.value.startswith(b"fwd_fast")
+    lib.nfp_reload_env()
+    assert lib.nfp_plan(ctypes.byref(d), 0, buf, len(buf)) == 0 and buf.value.startswith(b"fwd_pairs")
+    monkeypatch.delenv("NFP_FORCE_GENERIC")
+    lib.nfp_reload_env()
+    assert lib.nfp_plan(ctypes.byref(d), 0, buf, len(buf)) == 0 and buf.value.startswith(b"fwd_fast")

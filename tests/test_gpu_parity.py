@@ -14,7 +14,7 @@ import pytest
 import torch
 
 import cases as K
-from conftest import load_golden, rel_err, same_nan_pattern
+from conftest import load_golden, nfp_switch, rel_err, same_nan_pattern
 
 pytestmark = pytest.mark.gpu
 
@@ -67,10 +67,10 @@ def variant(request, monkeypatch):
     any-geometry kernels of nfp_gather.h (fwd_pairs / bwd_gather); 'atomic' forces their fallbacks for maps
     too large for those kernels' LDS tables (chunked scalar forward, LDS-atomic backward) — every
     implementation is held to the same bar on every case."""
-    monkeypatch.setenv("NFP_FORCE_GENERIC", "0" if request.param == "auto" else "1")
-    monkeypatch.setenv("NFP_BWD_ATOMIC", "1" if request.param == "atomic" else "0")
-    monkeypatch.setenv("NFP_FWD_SCALAR", "1" if request.param == "atomic" else "0")
-    monkeypatch.delenv("NFP_BWD_BANDS", raising=False)
+    nfp_switch(monkeypatch, "NFP_FORCE_GENERIC", "0" if request.param == "auto" else "1")
+    nfp_switch(monkeypatch, "NFP_BWD_ATOMIC", "1" if request.param == "atomic" else "0")
+    nfp_switch(monkeypatch, "NFP_FWD_SCALAR", "1" if request.param == "atomic" else "0")
+    nfp_switch(monkeypatch, "NFP_BWD_BANDS", None)
     return request.param
 
 
@@ -149,8 +149,10 @@ def test_unbuilt_measure_fails_loudly(dev):
         out = NFPPooling(c["shape"][1], **c["ctor"])(torch.from_numpy(K.make_input(c)).to(dev))
     assert _launches() == n0
     assert rel_err(out.cpu().numpy(), load_golden("m_scs_p2")["out"]) <= TOL
-    with pytest.raises(_abi.NfpUnsupported):
+    n0 = _launches()
+    with pytest.raises(_abi.NfpUnsupported, match="float32 or bfloat16"):   # refused before anything is launched
         NFPPooling(8, padding=1, measure="cosine")(torch.randn(1, 8, 5, 5, device=dev, dtype=torch.float16))
+    assert _launches() == n0
     for p in (float("inf"), 0, -2):           # LA.norm orders with other semantics: refused, never mis-computed
         with pytest.raises(_abi.NfpUnsupported, match="norm order"):
             NFPPooling(8, padding=1, measure="norm", p=p)(torch.randn(1, 8, 5, 5, device=dev))
@@ -366,7 +368,16 @@ def test_vit_tiny_nfp_bf16_k5_l2_step(dev):
     losses = [step(x, y).item() for _ in range(3)]
     torch.cuda.synchronize()
     assert all(np.isfinite(losses))
-    assert _abi.load().nfp_last_variant().decode().startswith("bwd_fast<R2,l2,bf16")
+    # the ViT head hands NFP a channels-last VIEW of the token matrix (batch stride (1+196)*192): read in place
+    bv = _abi.load().nfp_last_variant().decode()
+    assert bv.startswith("bwd_fast<R2,l2,bf16,nhwc"), bv
+    tok = torch.randn(8, 197, 192, device=dev, dtype=torch.bfloat16)
+    view = tok[:, 1:].transpose(1, 2).unflatten(2, (14, 14))
+    assert not view.is_contiguous() and not view.is_contiguous(memory_format=torch.channels_last)
+    out = layer(view)
+    fv = _abi.load().nfp_last_variant().decode()
+    assert fv.startswith("fwd_gram<R2,l2,bf16,nhwc"), fv
+    assert torch.equal(out, layer(view.contiguous(memory_format=torch.channels_last)))
 
 
 # ---- fused nfp_pooling tail (models/NFP_Pooling.py:27-31) ----------------------------
@@ -393,9 +404,11 @@ def test_fused_pool_matches_composition(shape, ctor, dev):
     gg = torch.from_numpy(feature_map(tuple(gap.shape), 92)).to(dev)
     gn = torch.from_numpy(feature_map(tuple(nfpm.shape), 93)).to(dev)
     ((gap * gg).sum() + (nfpm * gn).sum()).backward()
+    torch.cuda.synchronize()
+    bv = _abi.load().nfp_last_variant().decode()
+    assert bv.startswith("bwd_fast<") and bv.endswith(",pool>"), bv
     ((ref_gap * gg).sum() + (ref_nfpm * gn).sum()).backward()
     torch.cuda.synchronize()
-    assert _abi.load().nfp_last_variant().decode().startswith("bwd_fast") or True
     assert rel_err(x1.grad.cpu().numpy(), x2.grad.cpu().numpy()) <= 1e-5
 
 
@@ -540,9 +553,9 @@ def test_gather_backward_geometry_sweep(B, C, H, W, R, pad, stride, dil, mode, m
     a multiple of 4 — against the float64 formulation, bitwise reproducible, and equal to the atomic fallback."""
     from neighbour_feature_pooling_amd import NFPPooling, _abi
     from neighbour_feature_pooling_amd._host import nfp_host
-    monkeypatch.setenv("NFP_FORCE_GENERIC", "1")
-    monkeypatch.setenv("NFP_BWD_ATOMIC", "0")
-    monkeypatch.setenv("NFP_FWD_SCALAR", "0")
+    nfp_switch(monkeypatch, "NFP_FORCE_GENERIC", "1")
+    nfp_switch(monkeypatch, "NFP_BWD_ATOMIC", "0")
+    nfp_switch(monkeypatch, "NFP_FWD_SCALAR", "0")
     ctor = dict(R=R, measure=meas, padding=pad, stride=stride, dilation=dil, padding_mode=mode)
     if meas == "norm":
         ctor["p"] = 1
@@ -563,13 +576,13 @@ def test_gather_backward_geometry_sweep(B, C, H, W, R, pad, stride, dil, mode, m
     assert rel_err(out.detach().cpu().numpy(), ref.detach().cpu().numpy()) <= TOL
     assert rel_err(gx.cpu().numpy(), gref.cpu().numpy()) <= 2 * TOL
     # the banded kernel (maps too large for whole-image tables), forced here onto 3 bands of rows
-    monkeypatch.setenv("NFP_BWD_BANDS", "3")
+    nfp_switch(monkeypatch, "NFP_BWD_BANDS", "3")
     gxb, = torch.autograd.grad(out, x, go, retain_graph=True)
     assert _abi.load().nfp_last_variant().decode() in ("bwd_gather_banded", "bwd_generic")
     assert rel_err(gxb.cpu().numpy(), gref.cpu().numpy()) <= 2 * TOL
-    monkeypatch.delenv("NFP_BWD_BANDS")
-    monkeypatch.setenv("NFP_BWD_ATOMIC", "1")
-    monkeypatch.setenv("NFP_FWD_SCALAR", "1")
+    nfp_switch(monkeypatch, "NFP_BWD_BANDS", None)
+    nfp_switch(monkeypatch, "NFP_BWD_ATOMIC", "1")
+    nfp_switch(monkeypatch, "NFP_FWD_SCALAR", "1")
     gx3, = torch.autograd.grad(out, x, go)
     assert _abi.load().nfp_last_variant().decode() == "bwd_generic"
     assert rel_err(gx3.cpu().numpy(), gref.cpu().numpy()) <= 2 * TOL
@@ -638,12 +651,12 @@ def test_random_geometry_stress(dev, monkeypatch):
         if rnd.random() < 0.3:
             x = x.contiguous(memory_format=torch.channels_last)
         x.requires_grad_(True)
-        monkeypatch.delenv("NFP_BWD_BANDS", raising=False)
+        nfp_switch(monkeypatch, "NFP_BWD_BANDS", None)
         out = m(x)
         go = torch.randn(out.shape, generator=g).to(dev)
         gx, = torch.autograd.grad(out, x, go, retain_graph=True)
         variants.add(_abi.load().nfp_last_variant().decode().split("<")[0])
-        monkeypatch.setenv("NFP_BWD_BANDS", "2")
+        nfp_switch(monkeypatch, "NFP_BWD_BANDS", "2")
         gxb, = torch.autograd.grad(out, x, go)
         variants.add(_abi.load().nfp_last_variant().decode().split("<")[0])
         x64 = x.detach().double().requires_grad_(True)
@@ -686,7 +699,7 @@ def test_matrix_core_forward_bf16(B, C, H, W, R, meas, mode, kind, dev, monkeypa
     outputs may differ by at most one bf16 ulp, rarely — and with the float64 formulation to bf16 precision."""
     from neighbour_feature_pooling_amd import NFPPooling, _abi
     from neighbour_feature_pooling_amd._host import nfp_host
-    monkeypatch.setenv("NFP_FORCE_GENERIC", "0")
+    nfp_switch(monkeypatch, "NFP_FORCE_GENERIC", "0")
     ctor = dict(R=R, measure=meas, padding=R, padding_mode=mode)
     if meas == "norm":
         ctor["p"] = 2
@@ -703,13 +716,13 @@ def test_matrix_core_forward_bf16(B, C, H, W, R, meas, mode, kind, dev, monkeypa
     if kind != "nchw":
         x = x.contiguous(memory_format=torch.channels_last)
     x.requires_grad_(True)
-    monkeypatch.setenv("NFP_MFMA", "1")
+    nfp_switch(monkeypatch, "NFP_MFMA", "1")
     n0 = _launches()
     out = m(x)
     assert _abi.load().nfp_last_variant().decode().startswith("fwd_gram<"), _abi.load().nfp_last_variant()
     assert _launches() == n0 + 1
     assert torch.equal(out, m(x))                                   # deterministic
-    monkeypatch.setenv("NFP_MFMA", "0")
+    nfp_switch(monkeypatch, "NFP_MFMA", "0")
     out_v = m(x)
     assert _abi.load().nfp_last_variant().decode().startswith("fwd_fast<")
     ref = nfp_host(x.detach().double(), m.config)
@@ -721,7 +734,7 @@ def test_matrix_core_forward_bf16(B, C, H, W, R, meas, mode, kind, dev, monkeypa
     if kind == "const":
         assert out[:, :, 1:-1, 1:-1].abs().max().item() == 0.0 if R == 1 else True
     # the backward: phase B on the matrix cores too (when C % 32 == 0), against the vector kernel and float64
-    monkeypatch.setenv("NFP_MFMA", "1")
+    nfp_switch(monkeypatch, "NFP_MFMA", "1")
     go = torch.randn(out.shape, generator=g).to(dev).bfloat16()
     o1 = m(x)
     gx, = torch.autograd.grad(o1, x, go, retain_graph=True)
@@ -730,13 +743,199 @@ def test_matrix_core_forward_bf16(B, C, H, W, R, meas, mode, kind, dev, monkeypa
         assert bv.endswith(",mfma>"), bv          # (maps whose phase-A tables exceed LDS go to the general kernels)
         gx2, = torch.autograd.grad(o1, x, go, retain_graph=True)
         assert torch.equal(gx, gx2)                                  # deterministic
-        monkeypatch.setenv("NFP_MFMA", "0")
+        nfp_switch(monkeypatch, "NFP_MFMA", "0")
         gv, = torch.autograd.grad(o1, x, go)
         assert not _abi.load().nfp_last_variant().decode().endswith(",mfma>")
-        monkeypatch.setenv("NFP_MFMA", "1")
+        nfp_switch(monkeypatch, "NFP_MFMA", "1")
         if kind not in ("const", "smooth"):
             assert (gx.float() - gv.float()).abs().max().item() <= 2 ** -6 * gv.float().abs().max().item()
     x64 = x.detach().double().requires_grad_(True)
     gref, = torch.autograd.grad(nfp_host(x64, m.config), x64, go.double())
     if kind not in ("const", "smooth"):                               # (those have |out| ~ 0: sqrt'(0))
         assert rel_err(gx.float().cpu().numpy(), gref.float().cpu().numpy()) <= 2e-2
+
+
+# ---- the BASELINE.json workloads themselves (configs[3], configs[4]) against the oracle ------------------------
+
+def _oracle_pair(oracle_lib, x_np, go_np, ctor):
+    return oracle_lib.forward(x_np, **ctor), oracle_lib.backward(x_np, go_np, **ctor)
+
+
+@pytest.mark.parametrize("kind", ["randn", "relu"])
+def test_config4_nfp_shape_f32_against_oracle(kind, dev, oracle_lib):
+    """configs[3]: ResNet18+NFP at 224x224, bs 256 per GPU => NFP sees [256,512,7,7] f32 (NCHW), cosine k=3,
+    through the default dispatch; out and grad_x against the CPU oracle, <= 1e-5 of the tensor's max magnitude."""
+    from neighbour_feature_pooling_amd import NFPPooling, _abi
+    from neighbour_feature_pooling_amd.synth import feature_map
+    ctor = dict(R=1, measure="cosine", padding=1)
+    xh = feature_map((256, 512, 7, 7), 401)
+    if kind == "relu":
+        xh = np.maximum(xh, 0).astype(np.float32)
+    goh = feature_map((256, 8, 7, 7), 402)
+    x = torch.from_numpy(xh).to(dev).requires_grad_(True)
+    n0 = _launches()
+    out = NFPPooling(512, **ctor)(x)
+    assert _abi.load().nfp_last_variant().decode().startswith("fwd_")
+    fv = _abi.load().nfp_last_variant().decode()
+    out.backward(torch.from_numpy(goh).to(dev))
+    torch.cuda.synchronize()
+    bv = _abi.load().nfp_last_variant().decode()
+    assert _launches() == n0 + 2 and fv.startswith("fwd_fast<R1,cos,f32,nchw") and bv.startswith("bwd_fast<R1,cos,f32,nchw")
+    ref_out, ref_gx = _oracle_pair(oracle_lib, xh, goh, ctor)
+    assert rel_err(out.detach().cpu().numpy(), ref_out) <= TOL
+    assert rel_err(x.grad.cpu().numpy(), ref_gx) <= TOL
+
+
+@pytest.mark.parametrize("kind,scale", [("randn", None), ("smooth", 0.01), ("smooth", 0.002)])
+def test_config5_nfp_shape_bf16_channels_last_against_oracle(kind, scale, dev, oracle_lib):
+    """configs[4]: ViT-Tiny tokens => NFP sees [256,192,14,14] bf16 channels-last, k=5, L2, on the matrix-core
+    kernels (fwd_gram, bwd_fast<...,mfma>).  Oracle on the SAME bf16-rounded inputs; bf16 bound: out within 1e-2 and
+    grad_x within 2e-2 of the tensor's max magnitude (one bf16 rounding of out; the backward reads that rounded
+    out).  'smooth' = neighbours nearly identical, where G_pp + G_qq - 2 G_pq cancels: gradients are checked there
+    too, at the same bound."""
+    from neighbour_feature_pooling_amd import NFPPooling, _abi
+    from neighbour_feature_pooling_amd.synth import feature_map
+    ctor = dict(R=2, measure="norm", p=2, padding=2)
+    xh = feature_map((256, 192, 14, 14), 501)
+    if kind == "smooth":
+        xh = (xh.mean(axis=(2, 3), keepdims=True) + scale * xh).astype(np.float32)
+    xh = K._bf16_round(xh)
+    goh = K._bf16_round(feature_map((256, 24, 14, 14), 502))
+    x = torch.from_numpy(xh).to(dev).bfloat16().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    n0 = _launches()
+    out = NFPPooling(192, **ctor)(x)
+    fv = _abi.load().nfp_last_variant().decode()
+    out.backward(torch.from_numpy(goh).to(dev).bfloat16())
+    torch.cuda.synchronize()
+    bv = _abi.load().nfp_last_variant().decode()
+    assert _launches() == n0 + 2
+    assert fv.startswith("fwd_gram<R2,l2,bf16,nhwc"), fv
+    assert bv.startswith("bwd_fast<R2,l2,bf16,nhwc,mfma"), bv
+    assert x.grad.is_contiguous(memory_format=torch.channels_last)
+    ref_out, ref_gx = _oracle_pair(oracle_lib, xh, goh, ctor)
+    assert rel_err(out.detach().float().cpu().numpy(), ref_out) <= 1e-2
+    assert rel_err(x.grad.float().cpu().numpy(), ref_gx) <= 2e-2
+
+
+def test_attention_bf16_and_batch_strided_views(dev, oracle_lib):
+    """nfp.py:195-205 follows the input dtype: Attention on bf16 maps (raw dots kept in f32 scratch, probabilities
+    rounded once); and a batch-strided NCHW view is read in place with a dense gradient."""
+    from neighbour_feature_pooling_amd import NFPPooling, _abi
+    from neighbour_feature_pooling_amd.synth import feature_map
+    ctor = dict(R=1, measure="attention", padding=1)
+    xh = K._bf16_round(feature_map((3, 32, 6, 5), 601) * 0.5)
+    goh = K._bf16_round(feature_map((3, 8, 6, 5), 602))
+    x = torch.from_numpy(xh).to(dev).bfloat16().requires_grad_(True)
+    m = NFPPooling(32, **ctor)
+    with torch.no_grad():
+        o_ng = m(x)
+    out = m(x)
+    assert torch.equal(out, o_ng)
+    out.backward(torch.from_numpy(goh).to(dev).bfloat16())
+    ref_out, ref_gx = _oracle_pair(oracle_lib, xh, goh, ctor)
+    assert rel_err(out.detach().float().cpu().numpy(), ref_out) <= 1e-2
+    assert rel_err(x.grad.float().cpu().numpy(), ref_gx) <= 2e-2
+    # batch-strided NCHW view (every other image of a larger buffer)
+    big = torch.from_numpy(feature_map((8, 64, 7, 7), 603)).to(dev)
+    view = big[::2].requires_grad_(True)
+    assert not view.is_contiguous()
+    mc = NFPPooling(64, R=1, measure="cosine", padding=1)
+    o1 = mc(view)
+    assert _abi.load().nfp_last_variant().decode().startswith("fwd_fast<R1,cos,f32,nchw")
+    g1, = torch.autograd.grad(o1, view, torch.ones_like(o1))
+    dense = big[::2].contiguous().requires_grad_(True)
+    o2 = mc(dense)
+    g2, = torch.autograd.grad(o2, dense, torch.ones_like(o2))
+    assert torch.equal(o1, o2) and torch.equal(g1, g2) and g1.is_contiguous()
+
+
+def test_forward_refuses_when_backward_is_not_served(dev):
+    """Forward and backward envelopes differ for a few shapes; a call that will need a gradient must fail in forward(),
+    not inside loss.backward() — and run fine under no_grad."""
+    import ctypes
+    from neighbour_feature_pooling_amd import NFPPooling, _abi, functional
+    L = _abi.load()
+    found = None
+    for (C, H, W, R) in [(4, 400, 400, 1), (4, 300, 300, 2), (4, 200, 200, 3), (8, 160, 160, 1)]:
+        x = torch.zeros(1, C, H, W, device=dev)
+        cfg = NFPPooling(C, R=R, measure="cosine", padding=R).config
+        try:
+            d = functional.make_desc(x, cfg)
+        except _abi.NfpError:
+            continue
+        buf = ctypes.create_string_buffer(1024)
+        if L.nfp_plan(ctypes.byref(d), 0, buf, 1024) == 0 and L.nfp_plan(ctypes.byref(d), 1, buf, 1024) != 0:
+            found = (C, H, W, R)
+            break
+    if found is None:
+        pytest.skip("every probed shape is served by both passes")
+    C, H, W, R = found
+    m = NFPPooling(C, R=R, measure="cosine", padding=R)
+    x = torch.randn(1, C, H, W, device=dev, requires_grad=True)
+    n0 = _launches()
+    with pytest.raises(_abi.NfpUnsupported, match="backward is not"):
+        m(x)
+    assert _launches() == n0
+    with torch.no_grad():
+        assert m(x).shape == (1, (2 * R + 1) ** 2 - 1, H, W)
+
+
+# ---- configs[3] / configs[4] end to end: DDP over an RCCL process group (world size 1 on this box) ---------------
+
+@pytest.fixture(scope="module")
+def rccl_group(dev):
+    import socket
+    import torch.distributed as dist
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=dev)
+    yield dist
+    dist.destroy_process_group()
+
+
+def _ddp_step(net, x, y, dev, steps=2):
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    from neighbour_feature_pooling_amd import _abi
+    from neighbour_feature_pooling_amd.train import make_step
+    ddp = DDP(net, device_ids=[dev.index], gradient_as_bucket_view=True)
+    step, _ = make_step(ddp)
+    n0 = _abi.load().nfp_launch_count()
+    losses = [step(x, y).item() for _ in range(steps)]
+    torch.cuda.synchronize()
+    assert _abi.load().nfp_launch_count() >= n0 + 2 * steps, "the HIP NFP kernels did not run inside the DDP step"
+    assert all(np.isfinite(losses)), losses
+    for p in ddp.parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all()
+    return losses
+
+
+def test_config4_resnet18_nfp_ddp_step_rccl_224(dev, rccl_group):
+    """configs[3]: ResNet18+NFP(cosine), [256,3,224,224] per GPU, DistributedDataParallel on an RCCL ("nccl") group."""
+    from neighbour_feature_pooling_amd import _abi
+    from neighbour_feature_pooling_amd.train import build, synthetic_batch
+    assert rccl_group.get_backend() == "nccl"
+    torch.manual_seed(0)
+    net = build("resnet18", num_classes=10, in_chans=3, image=224, device=dev)
+    x, y = synthetic_batch(256, 3, 224, 10, dev, torch.float32, 11)
+    _ddp_step(net, x, y, dev)
+    bv = _abi.load().nfp_last_variant().decode()
+    assert bv.startswith("bwd_fast<R1,cos,f32,nchw"), bv      # NFP saw [256,512,7,7]
+    t = torch.ones(4, device=dev)
+    rccl_group.all_reduce(t)                                    # the collective DDP's buckets use, on this group
+    assert t.sum().item() == 4.0
+
+
+def test_config5_vit_tiny_nfp_bf16_ddp_step_rccl_bs256(dev, rccl_group):
+    """configs[4]: ViT-Tiny + NFP(k=5, L2) head on 14x14x192 tokens, bf16, bs 256, DDP on the RCCL group."""
+    from neighbour_feature_pooling_amd import NFPPooling, _abi
+    from neighbour_feature_pooling_amd.train import build, synthetic_batch
+    torch.manual_seed(0)
+    layer = NFPPooling(192, R=2, measure="norm", p=2, padding=2)
+    net = build("vit_tiny_patch16_224", num_classes=10, in_chans=3, image=224, nfp=layer, device=dev,
+                dtype=torch.bfloat16)
+    x, y = synthetic_batch(256, 3, 224, 10, dev, torch.bfloat16, 12)
+    _ddp_step(net, x, y, dev)
+    bv = _abi.load().nfp_last_variant().decode()
+    assert bv.startswith("bwd_fast<R2,l2,bf16,nhwc"), bv

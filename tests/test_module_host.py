@@ -100,3 +100,42 @@ def test_nfp_pooling_wrapper_matches_reference():
     assert rel_err(w.nfp_proj.weight.grad.numpy(), g["gw"]) <= 1e-5
     assert rel_err(w.nfp_proj.bias.grad.numpy(), g["gb"]) <= 1e-5
     assert nfp_pooling().nfp_proj is None  # NFP_Pooling.py:23
+
+
+def test_inner_layout_and_canonical_strides():
+    """functional._dense: images dense in NCHW or channels-last order are read in place whatever the batch stride
+    (ViT tokens behind a class token, texture_pooling.py:181-188); anything else is copied to NCHW once."""
+    from neighbour_feature_pooling_amd import functional as F
+    x = torch.randn(4, 8, 5, 6)
+    assert F._dense(x)[1] == "nchw" and F._dense(x)[0] is x
+    xl = x.contiguous(memory_format=torch.channels_last)
+    assert F._dense(xl)[1] == "nhwc" and F._dense(xl)[0] is xl
+    tok = torch.randn(4, 1 + 30, 8)
+    view = tok[:, 1:].transpose(1, 2).unflatten(2, (5, 6))
+    assert not view.is_contiguous(memory_format=torch.channels_last)
+    v, lay = F._dense(view)
+    assert v is view and lay == "nhwc"
+    assert F._canonical_strides(v, lay) == (31 * 8, 1, 6 * 8, 8)
+    every_other = torch.randn(8, 8, 5, 6)[::2]
+    v, lay = F._dense(every_other)
+    assert v is every_other and lay == "nchw" and F._canonical_strides(v, lay) == (2 * 240, 30, 6, 1)
+    sliced = x[:, :, :, ::2]                       # not dense inside an image: copied
+    v, lay = F._dense(sliced)
+    assert v is not sliced and v.is_contiguous() and lay == "nchw"
+    expanded = torch.randn(1, 8, 5, 6).expand(3, 8, 5, 6)   # batch stride 0: images overlap, copied
+    assert F._dense(expanded)[0].is_contiguous() and F._dense(expanded)[0] is not expanded
+    one = torch.randn(1, 1, 1, 1)                  # size-1 dimensions: arbitrary strides in torch, canonical here
+    assert F._canonical_strides(*F._dense(one)) == (1, 1, 1, 1)
+    d = F.make_desc(view, F.NfpConfig(R=1, measure="cosine", padding=1))
+    assert (d.sxB, d.sxC, d.sxH, d.sxW, d.sgB) == (248, 1, 48, 8, 240)
+
+
+def test_plan_cache_is_lru():
+    from neighbour_feature_pooling_amd import functional as F
+    F._PLANS.clear()
+    for i in range(F._PLANS_MAX + 10):
+        F._plans_put(("k", i), i)
+        F._plans_get(("k", 0))                     # keep the first entry hot
+    assert len(F._PLANS) == F._PLANS_MAX
+    assert F._plans_get(("k", 0)) == 0 and F._plans_get(("k", 1)) is None
+    F._PLANS.clear()
