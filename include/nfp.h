@@ -87,10 +87,27 @@ typedef struct nfp_desc {
                                 images are dense but spaced apart (ViT tokens behind a class
                                 token, texture_pooling.py:181-188) is read in place and still
                                 gets a dense gradient                                       */
+  const void* ws;            /* DEVICE pointer to the descriptor's constant tables, filled by
+                                nfp_workspace_init, or NULL.  The hot-path kernels (stride 1,
+                                pad = R, cosine / L2) read their index maps from it; without it
+                                the call is served by the general kernels                   */
 } nfp_desc;
 
 int nfp_abi_version(void);
 const char* nfp_last_error(void);
+
+/*
+ * Constant tables of a descriptor.  What the reference re-derives inside every conv call — which input pixel each
+ * kernel tap reads under the padding mode (nn.Conv2d's padding_mode, nfp.py:42-58) — depends only on
+ * (H, W, R, pad, stride, dilation, pad_mode), not on the batch, the channels or the data.  The hot-path kernels read
+ * it from a table instead of recomputing it per launch:
+ *   bytes = nfp_workspace_bytes(d)        0 = this descriptor has no table-driven kernels
+ *   nfp_workspace_init(d, ws, stream)     enqueue the fill of `ws` (>= bytes, 16-byte aligned, caller-owned)
+ * then set d->ws = ws for nfp_forward / nfp_backward / nfp_pool_*.  One buffer serves every descriptor that
+ * differs only in B, C, measure, similarity, dtype, strides, p, eps (the tables do not depend on them).
+ */
+int64_t nfp_workspace_bytes(const nfp_desc* d);
+int nfp_workspace_init(const nfp_desc* d, void* ws, void* hip_stream);
 
 /* out is [B, N, Ho, Wo] contiguous; Ho/Wo as nn.Conv2d computes them
  * (nfp.py:125-130 is the square-only helper of the same formula). */

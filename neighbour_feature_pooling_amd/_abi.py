@@ -19,7 +19,7 @@ F32, BF16 = 0, 1
 
 EXPORTS = ["nfp_abi_version", "nfp_last_error", "nfp_output_shape", "nfp_saved_floats", "nfp_forward",
            "nfp_backward", "nfp_pool_supported", "nfp_pool_forward", "nfp_pool_backward", "nfp_launch_count",
-           "nfp_last_variant", "nfp_plan", "nfp_reload_env"]
+           "nfp_last_variant", "nfp_plan", "nfp_reload_env", "nfp_workspace_bytes", "nfp_workspace_init"]
 
 
 class NfpDesc(ctypes.Structure):
@@ -28,7 +28,7 @@ class NfpDesc(ctypes.Structure):
                 ("B", "C", "H", "W", "R", "pad", "stride", "dilation", "pad_mode", "measure",
                  "similarity", "diff_weights", "dtype")] + \
                [("p", ctypes.c_float), ("eps", ctypes.c_float), ("q_scs", ctypes.c_float)] + \
-               [(n, ctypes.c_int64) for n in ("sxB", "sxC", "sxH", "sxW", "sgB")]
+               [(n, ctypes.c_int64) for n in ("sxB", "sxC", "sxH", "sxW", "sgB")] + [("ws", ctypes.c_void_p)]
 
 
 class NfpError(RuntimeError):
@@ -64,6 +64,9 @@ def load():
     L.nfp_output_shape.argtypes = [dp, i32p, i32p, i32p]
     L.nfp_saved_floats.argtypes = [dp]
     L.nfp_saved_floats.restype = ctypes.c_int64
+    L.nfp_workspace_bytes.argtypes = [dp]
+    L.nfp_workspace_bytes.restype = ctypes.c_int64
+    L.nfp_workspace_init.argtypes = [dp, vp, vp]
     L.nfp_forward.argtypes = [dp, vp, vp, vp, vp]
     L.nfp_backward.argtypes = [dp, vp, vp, vp, vp, vp, vp]
     L.nfp_pool_supported.argtypes = [dp]

@@ -24,6 +24,7 @@ struct KP {
   float p, eps, q_scs;
   long long sB, sC, sH, sW;  // element strides of x; grad_x shares sC / sH / sW
   long long gB;              // batch stride of grad_x (a batch-strided view of x gets a dense gradient)
+  const unsigned char* ws;   // the descriptor's constant tables (nfp_tables.h) or null
   int contig;                // x is NCHW-contiguous
   // launch shape
   int Cc;   // channels per LDS chunk
@@ -31,6 +32,7 @@ struct KP {
   int Ow;   // outputs per workgroup (fwd) / per batch (bwd)
   int Cwg;  // bwd: channels per workgroup
   int Tc;   // bwd generic: channel lanes per output
+  int early;  // bwd_fast: the x slab lies beside the pair values (not over them): committed during phase A
   // host-computed reciprocals (hot path: exact small-integer division by float multiply)
   float invP, invW, invNQ, invPT, inv_eps;
 };

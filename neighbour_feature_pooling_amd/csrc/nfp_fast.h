@@ -25,7 +25,7 @@
 // thread in a fixed order, so the result is bitwise reproducible and no atomics are used;
 // the padding adjoint is folded into Wm.  Then one pass: read x slab, write grad_x.
 #pragma once
-#include "nfp_measures.h"
+#include "nfp_tables.h"
 
 namespace nfp {
 
@@ -51,63 +51,6 @@ constexpr int kRN = 4;    // channels-last staging: slots per thread per chunk
 constexpr int kFwdThreads = NFP_FWD_THREADS;  // every instruction costs (waves per SIMD) x 2 clk of CU issue time
 constexpr int kBwdThreads = NFP_BWD_THREADS;  // backward keeps (2R+1)^2 weights + offsets + staged x in registers
 
-template <int R>
-struct Win {
-  static constexpr int K = 2 * R + 1, K2 = K * K, N = K2 - 1, NF = N / 2;
-};
-
-// forward direction d in [0, NF): (0,1..R), then rows dy=1..R with dx=-R..R
-template <int R>
-__device__ __forceinline__ void fdir(int d, int& dy, int& dx) {
-  if (d < R) {
-    dy = 0;
-    dx = d + 1;
-  } else {
-    int e = d - R;
-    dy = 1 + e / (2 * R + 1);
-    dx = e % (2 * R + 1) - R;
-  }
-}
-template <int R>
-__device__ __forceinline__ int fidx(int dy, int dx) {
-  return dy == 0 ? dx - 1 : R + (dy - 1) * (2 * R + 1) + (dx + R);
-}
-
-// Per-thread neighbour maps for stride 1 / dilation 1 / pad R: my[k] / mx[k] = mapped row / column
-// of kernel tap k for the thread's pixel (branch-free, computed once); any neighbour n is then two
-// register selects.
-template <int R>
-struct NbrMap {
-  static constexpr int K = 2 * R + 1;
-  int my[K], mx[K];
-  __device__ __forceinline__ void init(const KP& g, int py, int px) {
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-      my[k] = map_index_bf(py + k - R, g.H, g.mode);
-      mx[k] = map_index_bf(px + k - R, g.W, g.mode);
-    }
-  }
-  __device__ __forceinline__ int get(const KP& g, int n, int& qy, int& qx) const {
-    const int tp = n + (n >= (K * K) / 2 ? 1 : 0);
-    const int ky = tp / K, kx = tp - ky * K;  // K is a compile-time constant
-    qy = my[0];
-    qx = mx[0];
-#pragma unroll
-    for (int k = 1; k < K; ++k) {
-      qy = ky == k ? my[k] : qy;
-      qx = kx == k ? mx[k] : qx;
-    }
-    return (qy < 0 || qx < 0) ? -1 : qy * g.W + qx;
-  }
-};
-
-// LDS slot of pixel p inside a channel-quad row (row stride Pp = P rounded up to 4 slots): pixels are
-// rotated inside their group of four by (p >> 3) & 3.  The NCHW staging writes a 4-pixel block per
-// lane, i.e. lanes 64 B apart; unrotated that is a 4-way bank conflict on every ds_write_b128
-// (measured: half of all LDS cycles); rotated, each 8-lane write group covers all 32 banks.  Reads
-// of consecutive pixels stay conflict-free (a permutation inside each 64-byte group).
-__device__ __forceinline__ int swz(int p) { return (p & ~3) | (((p & 3) + (p >> 3)) & 3); }
-
 // exact i / d for 0 <= i, quotient < 2048 (d >= 1): float multiply instead of the ~20-instruction
 // integer division sequence
 __device__ __forceinline__ int fast_div(int i, float inv_d) { return (int)(((float)i + 0.5f) * inv_d); }
@@ -120,6 +63,9 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 using Rsrc = __amdgpu_buffer_rsrc_t;
 constexpr int kAuxSc1 = 16;  // buffer-store cache policy: sc1 = write-through
+#ifndef NFP_BWD_STORE_AUX
+#define NFP_BWD_STORE_AUX kAuxSc1  // A/B knob (scripts/ab_flags.py)
+#endif
 __device__ __forceinline__ Rsrc make_rsrc(const void* base, long long bytes) {
   return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)(bytes > 0x7ffffff0LL ? 0x7ffffff0LL : bytes), 0x00020000);
 }
@@ -145,19 +91,19 @@ template <bool BF>
 __device__ __forceinline__ void store_px4(Rsrc r, int e, int srow, float4 v) {  // write-through
   if constexpr (!BF) {
     u32x4 u = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
-    __builtin_amdgcn_raw_buffer_store_b128(u, r, e * 4, srow * 4, kAuxSc1);
+    __builtin_amdgcn_raw_buffer_store_b128(u, r, e * 4, srow * 4, NFP_BWD_STORE_AUX);
   } else {
     u32x2 u = {(uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16),
                (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16)};
-    __builtin_amdgcn_raw_buffer_store_b64(u, r, e * 2, srow * 2, kAuxSc1);
+    __builtin_amdgcn_raw_buffer_store_b64(u, r, e * 2, srow * 2, NFP_BWD_STORE_AUX);
   }
 }
 template <bool BF>
 __device__ __forceinline__ void store_1(Rsrc r, int e, int srow, float v) {
   if constexpr (!BF)
-    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, e * 4, srow * 4, kAuxSc1);
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, e * 4, srow * 4, NFP_BWD_STORE_AUX);
   else
-    __builtin_amdgcn_raw_buffer_store_b16((short)f32_to_bf16(v), r, e * 2, srow * 2, kAuxSc1);
+    __builtin_amdgcn_raw_buffer_store_b16((short)f32_to_bf16(v), r, e * 2, srow * 2, NFP_BWD_STORE_AUX);
 }
 
 // Staged registers of one chunk.  Every load is unconditional (indices clamped onto valid slots);
@@ -654,6 +600,11 @@ __device__ __forceinline__ void bwd_gemm_phase(const KP& g, const float* Wt, uin
   }
 }
 
+template <int R>
+struct L_BRQ {
+  static constexpr int v = ((Win<R>::K2 + 7) & ~7) / 8;  // 16-byte pieces of a pixel's boff row (ws_layout: BR)
+};
+
 // ---- backward -------------------------------------------------------------------------------
 // POOL: grad_out is not a map but the gradients of the two pooled outputs: go[b,n,p] = gnfpm[b,n]/P
 // for every p, and every grad_x[b,c,p] also receives ggap[b,c]/P (adjoint of the two means).
@@ -662,24 +613,29 @@ __global__ void __launch_bounds__(GEMM ? 1024 : kBwdThreads) bwd_fast(const KP g
                                                         const void* __restrict__ go, const void* __restrict__ out,
                                                         const float* __restrict__ saved, void* __restrict__ gx,
                                                         const float* __restrict__ ggap,
-                                                        const float* __restrict__ gnfpm) {
+                                                        const float* __restrict__ gnfpm,
+                                                        const unsigned char* __restrict__ ws) {
   static_assert(!POOL || (!BF && !NHWC), "fused pooling tail: NCHW float32 only");
   static_assert(!GEMM || (BF && !POOL), "matrix-core phase B: bf16 storage only");
-  constexpr int K = Win<R>::K, K2 = Win<R>::K2, N = Win<R>::N;
+  constexpr int K2 = Win<R>::K2, N = Win<R>::N;
+  // the diagonal is folded by a phase of its own when the weights are consumed as a table (matrix cores) or the
+  // window is large; for k = 3 every compute thread folds its own pixel's nine terms while it loads its weights
+  constexpr bool FOLD_PHASE = GEMM || R != 1;
   extern __shared__ __attribute__((aligned(16))) float4 lds4[];
   const int P = g.P;
-  // LDS: Wt (lives to the end) | union { x slab , coefficient tables (dead once Wt is built) }
-  float* Wt = (float*)lds4;                    // [P][K2] gathered weights
-  float4* slab = lds4 + ((P * K2 + 3) >> 2);   // [Cc/4][P]
-  int* Qt = (int*)slab;                        // [P][N] neighbour pixel of (p, n), -1 = zero pad
-  float* CR = (float*)(Qt + P * N);            // [P][N] cross coefficient of pair (p, n)
-  float* SP = CR + P * N;                      // [P][N] self coefficient on the centre
-  float* SQ = SP + P * N;                      // [P][N] self coefficient on the neighbour
-  float* Sq2 = SQ + P * N;                     // [P][K2] neighbour-role self terms per window slot
+  // LDS: Wt | Dt | ipn | dfn (live to the end) | pair values | x slab.  The slab lies OVER the pair values (dead
+  // once Wt is built) when both do not fit side by side (g.early == 0).
+  float* Wt = (float*)lds4;        // [P][K2] gathered weights
+  float* Dt = Wt + P * K2;         // [P][K2] diagonal terms collected per slot
+  float* ipn = Dt + P * K2;        // [P] 1 / max(|x_p|, eps)
+  float* dfn = ipn + P;            // [P] -1 / (|x_p| max(|x_p|, eps)), 0 where |x_p| = 0
+  float4* pv4 = lds4 + ((2 * P * K2 + 2 * P + 3) >> 2);
+  float2* AD = (float2*)pv4;       // cosine: [N*P] {sg, sg*s} of pair o = n*P + p
+  float* CC = (float*)pv4;         // L2:     [N*P] c = -+g/d
+  float4* slab = g.early ? pv4 + (((M == NFP_COSINE ? 2 : 1) * N * P + 3) >> 2) : pv4;  // [Cc/4][P]
   const int b = blockIdx.x, t = threadIdx.x, T = blockDim.x;
   const int cb0 = blockIdx.y * g.Cwg, cb1 = min(g.C, cb0 + g.Cwg);
   const int gl = fast_div(t, g.invP), p = t - gl * P;
-  const int py = fast_div(p, g.invW), px = p - py * g.W;
   const bool active = gl < g.G;
   constexpr int DT = BF ? NFP_BF16 : NFP_F32;
   constexpr int ES = BF ? 2 : 4;
@@ -687,230 +643,178 @@ __global__ void __launch_bounds__(GEMM ? 1024 : kBwdThreads) bwd_fast(const KP g
   const Rsrc gxb = make_rsrc((char*)gx + (long long)b * g.gB * ES, (long long)g.C * P * ES);
   const void* gob = (const char*)go + (long long)b * N * P * ES;
   const void* outb = (const char*)out + (long long)b * N * P * ES;
+  const WsLayout L = ws_layout(P, R, g.mode);
+  const int LQ = L.LW >> 3;  // 16-byte pieces per link row
+  const uint4* lnk = (const uint4*)(ws + L.lnk);
+  const uint16_t* tqt = (const uint16_t*)(ws + L.tq);
 
   NFP_STAMP_INIT();
   NFP_STAMP(0);
-  // A1: per-pair coefficients -> LDS tables.  Thread (p, n = gl, gl+G, ...), four n per round with
-  // their loads batched.  The first round's loads are issued BEFORE the x chunk and the x chunk
-  // before the first round's arithmetic: loads return in issue order, so the coefficient phase
-  // starts after one memory latency while x streams in underneath it.
-  NbrMap<R> nm;
-  nm.init(g, py, px);
-  struct A1 {
-    float gv[4], ov[4], nqv[4];
-    int qn[4];
-  } a1;
-  const float* svb = (M == NFP_COSINE) ? saved + (long long)b * P : nullptr;
-  const float np_ = (M == NFP_COSINE) ? svb[p] : 0.f;
-  auto a1_load = [&](int n0) {
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int n = min(n0 + u * g.G, N - 1);
-      int qy, qx;
-      a1.qn[u] = nm.get(g, n, qy, qx);
-      a1.gv[u] = POOL ? gnfpm[(long long)b * N + n] * g.invP : ldx(gob, n * P + p, DT);
-      a1.ov[u] = ldx(outb, n * P + p, DT);
-      a1.nqv[u] = (M == NFP_COSINE) ? svb[max(a1.qn[u], 0)] : 0.f;
-    }
+  // Phase A, table driven (nfp_tables.h).  Loads are issued in the order their data is needed: the geometry tables
+  // and this image's grad_out / out / norms first (small, L2-resident), then the x chunk, so that the pair
+  // arithmetic runs while x streams in.  One table entry / pair per thread and round, the next round's loads in
+  // flight during the current round's arithmetic.
+  const int NE = P * K2, NO = N * P;
+  uint4 rw0, rw1;
+  uint32_t tqv;
+  auto rows_load = [&](int e) {
+    rw0 = lnk[(long long)e * LQ];
+    rw1 = lnk[(long long)e * LQ + LQ - 1];  // (unconditional: the same piece again when a row is one piece)
+    tqv = tqt[e];
   };
-  auto a1_math = [&](int n0) {
-    // pin the loaded values: hipcc otherwise re-issues ("rematerialises") some of these loads here and
-    // waits vmcnt(0) for them, which drains the x chunk that is still streaming in
-#pragma unroll
-    for (int u = 0; u < 4; ++u) asm volatile("" : "+v"(a1.gv[u]), "+v"(a1.ov[u]), "+v"(a1.nqv[u]));
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int n = n0 + u * g.G;
-      if (active && n < N) {
-        const int q = a1.qn[u];
-        float cr = 0.f, sp = 0.f, sq = 0.f;
-        if (M == NFP_COSINE) {
-          // 1/max(|.|,eps) and 1/|.| by v_rcp_f32 (1 ulp); 0 where the norm is 0 (torch's subgradient)
-          const float s = g.similarity ? a1.ov[u] : 1.f - a1.ov[u];
-          const float sg = g.similarity ? a1.gv[u] : -a1.gv[u];
-          const float nq = a1.nqv[u];
-          const float ip = __builtin_amdgcn_rcpf(fmaxf(np_, g.eps)), iq = __builtin_amdgcn_rcpf(fmaxf(nq, g.eps));
-          const float rp = np_ > 0.f ? __builtin_amdgcn_rcpf(np_) : 0.f, rq = nq > 0.f ? __builtin_amdgcn_rcpf(nq) : 0.f;
-          const float t0 = sg * ip;
-          cr = q >= 0 ? t0 * iq : 0.f;
-          sp = q >= 0 ? -t0 * s * rp : 0.f;
-          sq = q >= 0 ? -sg * s * iq * rq : 0.f;
-        } else {
-          const float d = fabsf(a1.ov[u]);
-          const float c = d == 0.f ? 0.f : (g.similarity ? -a1.gv[u] : a1.gv[u]) * __builtin_amdgcn_rcpf(d);
-          if (g.diff) {
-            sp = c;
-            cr = q >= 0 ? -c : 0.f;
-            sq = q >= 0 ? c : 0.f;
-          } else {
-            sq = q >= 0 ? c : 0.f;  // d|x_q| / dx_q only
-          }
-        }
-        Qt[p * N + n] = q;
-        CR[p * N + n] = cr;
-        SP[p * N + n] = sp;
-        SQ[p * N + n] = sq;
-      }
-    }
+  float gv, ov;
+  auto pair_load = [&](int o) {
+    gv = POOL ? gnfpm[(long long)b * N + fdivi(o, P)] * g.invP : ldx(gob, o, DT);
+    ov = ldx(outb, o, DT);
   };
-  a1_load(gl);
+  rows_load(min(t, NE - 1));
+  pair_load(min(t, NO - 1));
+  const float nrm = (M == NFP_COSINE) ? saved[(long long)b * P + min(t, P - 1)] : 0.f;
+  uint4 bo[L_BRQ<R>::v];  // this pixel's window offsets (phase B)
+  if constexpr (!GEMM) {
+    const uint4* bot = (const uint4*)(ws + L.boff) + (long long)p * L_BRQ<R>::v;
+#pragma unroll
+    for (int u = 0; u < L_BRQ<R>::v; ++u) bo[u] = bot[u];
+  }
   __builtin_amdgcn_sched_barrier(0);  // keep these (small, needed first) loads ahead of the x chunk
   Staged<NHWC> st;
   if constexpr (!GEMM) stage_issue<BF, NHWC>(st, xb, g, cb0, min(g.Cc, cb1 - cb0) >> 2, t, T, p, gl, active);
-  // nothing that consumes a loaded value may be scheduled above this line (hipcc otherwise hoists
-  // e.g. rcp(|x_p|) into the load sequence and stalls the remaining loads behind a vmcnt wait)
+  // nothing that consumes a loaded value may be scheduled above this line (hipcc otherwise hoists consumers into
+  // the load sequence and stalls the remaining loads behind a vmcnt wait)
   __builtin_amdgcn_sched_barrier(0);
   NFP_STAMP(1);
-  a1_math(gl);
-  for (int n0 = gl + 4 * g.G; n0 < N; n0 += 4 * g.G) {
-    a1_load(n0);
-    a1_math(n0);
+  // A1: per-pair values, in the memory order of grad_out / out
+  for (int o = t; o < NO; o += T) {
+    const float gc = gv, oc = ov;
+    if (o + T < NO) pair_load(o + T);
+    if (M == NFP_COSINE) {
+      const float s = g.similarity ? oc : 1.f - oc;
+      const float sg = g.similarity ? gc : -gc;
+      AD[o] = make_float2(sg, sg * s);
+    } else {
+      const float d = fabsf(oc);
+      CC[o] = d == 0.f ? 0.f : (g.similarity ? -gc : gc) * __builtin_amdgcn_rcpf(d);
+    }
+  }
+  if (M == NFP_COSINE && t < P) {
+    const float ip = __builtin_amdgcn_rcpf(fmaxf(nrm, g.eps));
+    ipn[t] = ip;
+    dfn[t] = nrm > 0.f ? -ip * __builtin_amdgcn_rcpf(nrm) : 0.f;
   }
   __syncthreads();
   NFP_STAMP(2);
-  if constexpr (R == 1) {
-    // A2: gather.  Thread (r = p, slot j = gl, gl+G, ...), t = r + delta_j if inside the image.
-    if (active) {
-      for (int j = gl; j < K2; j += g.G) {
-        const int jy = j / K, jx = j - jy * K;
-        const int ty = py + jy - R, tx = px + jx - R;
-        float w = 0.f, s2 = 0.f;
-        if (ty >= 0 && ty < g.H && tx >= 0 && tx < g.W) {
-          const int tt = ty * g.W + tx;
-          const int4* qa = (const int4*)(Qt + p * N);
-          const float4* ca = (const float4*)(CR + p * N);
-          const int4* qb = (const int4*)(Qt + tt * N);
-          const float4* cb = (const float4*)(CR + tt * N);
-          const float4* sb = (const float4*)(SQ + tt * N);
-  #pragma unroll
-          for (int m = 0; m < N / 4; ++m) {  // r as centre, tt as its neighbour
-            const int4 qq = qa[m];
-            const float4 cc = ca[m];
-            w += (qq.x == tt ? cc.x : 0.f) + (qq.y == tt ? cc.y : 0.f) + (qq.z == tt ? cc.z : 0.f) +
-                 (qq.w == tt ? cc.w : 0.f);
-          }
-  #pragma unroll
-          for (int m = 0; m < N / 4; ++m) {  // tt as centre, r as its neighbour
-            const int4 qq = qb[m];
-            const float4 cc = cb[m];
-            const float4 ss = sb[m];
-            w += (qq.x == p ? cc.x : 0.f) + (qq.y == p ? cc.y : 0.f) + (qq.z == p ? cc.z : 0.f) +
-                 (qq.w == p ? cc.w : 0.f);
-            s2 += (qq.x == p ? ss.x : 0.f) + (qq.y == p ? ss.y : 0.f) + (qq.z == p ? ss.z : 0.f) +
-                  (qq.w == p ? ss.w : 0.f);
-          }
-          if (tt == p) {
-            const float4* sa = (const float4*)(SP + p * N);
-  #pragma unroll
-            for (int m = 0; m < N / 4; ++m) {
-              const float4 ss = sa[m];
-              w += (ss.x + ss.y) + (ss.z + ss.w);
-            }
+  // A2: window entry (r, j) = the sum of the pairs that link r with the pixel under slot j, listed by the table
+  for (int e = t; e < NE; e += T) {
+    const uint4 r0 = rw0, r1 = rw1;
+    const uint32_t tqc = tqv;
+    if (e + T < NE) rows_load(e + T);
+    const int r = fdivi(e, K2), j = e - r * K2;
+    float S = 0.f, Dj = 0.f, wv;
+    if (j != K2 / 2) {
+      auto take = [&](uint32_t ent) {  // one list entry, predicated (the lists are packed: live entries first)
+        const bool on = ent != 0xFFFFu;
+        const int o = on ? (int)(ent & 0x7FFFu) : 0;
+        if (M == NFP_COSINE) {
+          const float2 v = AD[o];
+          S += on ? v.x : 0.f;
+          Dj += on ? v.y : 0.f;
+        } else {
+          const float cv = CC[o];
+          S += on ? cv : 0.f;
+          Dj += (on && (g.diff || (ent & 0x8000u))) ? cv : 0.f;  // 'Norm' quirk: neighbour-role terms only
+        }
+      };
+      auto live = [&](uint32_t w2) { return __ballot((w2 & 0xFFFFu) != 0xFFFFu) != 0; };  // wave-uniform
+      take(r0.x & 0xFFFFu);
+      take(r0.x >> 16);
+      if (live(r0.y)) {
+        take(r0.y & 0xFFFFu);
+        take(r0.y >> 16);
+        if (live(r0.z)) {
+          take(r0.z & 0xFFFFu);
+          take(r0.z >> 16);
+          take(r0.w & 0xFFFFu);
+          take(r0.w >> 16);
+          if (LQ > 1 && live(r1.x)) {
+            take(r1.x & 0xFFFFu);
+            take(r1.x >> 16);
+            take(r1.y & 0xFFFFu);
+            take(r1.y >> 16);
+            take(r1.z & 0xFFFFu);
+            take(r1.z >> 16);
+            take(r1.w & 0xFFFFu);
+            take(r1.w >> 16);
           }
         }
-        Wt[p * K2 + j] = w;
-        Sq2[p * K2 + j] = s2;
       }
-    }
-    __syncthreads();
-    NFP_STAMP(3);
-    // A3: fold the neighbour-role self terms into the diagonal, fixed order
-    if (gl == 0) {
-      float s = Wt[p * K2 + K2 / 2];
-  #pragma unroll
-      for (int j = 0; j < K2; ++j) s += Sq2[p * K2 + j];
-      Wt[p * K2 + K2 / 2] = s;
-    }
-    __syncthreads();
-    NFP_STAMP(4);
-  } else {
-    // Larger windows: the two-sided gather above costs 2N compares per table entry.  Instead bin each
-    // centre's own pairs by window slot — Out[r][j] = sum_{n: q(r,n) = r + delta_j} cross(r,n), same for the
-    // neighbour-self terms — and note that the pairs in which r is t's neighbour are exactly t's bin
-    // pointing back at r:  W[r][j] = Out[r][j] + Out[t][K2-1-j].  Every entry is still summed by one thread
-    // in a fixed order.
-    float* Out = Sq2 + P * K2;  // [P][K2]
-    float* Osq = Out + P * K2;  // [P][K2]
-    float* SPs = Osq + P * K2;  // [P]
-    if (active) {
-      // the pixel's own rows of the pair tables, read ONCE into registers: left inside the slot loop they are
-      // re-read for every slot (hipcc cannot hoist them past the Out / Osq stores) and this phase becomes
-      // LDS-bandwidth bound — 18 ds_read_b128 per (pixel, slot), 11 k cycles per workgroup at k = 5
-      int4 qr[N / 4];
-      float4 cr4[N / 4], sr4[N / 4];
-#pragma unroll
-      for (int m = 0; m < N / 4; ++m) {
-        qr[m] = ((const int4*)(Qt + p * N))[m];
-        cr4[m] = ((const float4*)(CR + p * N))[m];
-        sr4[m] = ((const float4*)(SQ + p * N))[m];
-      }
-      for (int j = gl; j < K2; j += g.G) {
-        const int jy = j / K, jx = j - jy * K;
-        const int ty = py + jy - R, tx = px + jx - R;
-        const bool inside = ty >= 0 && ty < g.H && tx >= 0 && tx < g.W;
-        const int tt = inside ? ty * g.W + tx : -2;
-        float o = 0.f, q2 = 0.f;
-#pragma unroll
-        for (int m = 0; m < N / 4; ++m) {
-          const int4 qq = qr[m];
-          const float4 cc = cr4[m], ss = sr4[m];
-          o += (qq.x == tt ? cc.x : 0.f) + (qq.y == tt ? cc.y : 0.f) + (qq.z == tt ? cc.z : 0.f) +
-               (qq.w == tt ? cc.w : 0.f);
-          q2 += (qq.x == tt ? ss.x : 0.f) + (qq.y == tt ? ss.y : 0.f) + (qq.z == tt ? ss.z : 0.f) +
-                (qq.w == tt ? ss.w : 0.f);
+      const int tt = tqc == 0xFFFFu ? r : (int)tqc;
+      wv = M == NFP_COSINE ? ipn[r] * ipn[tt] * S : (g.diff ? -S : 0.f);
+    } else {
+      // centre slot: its row carries the pixel's two tap masks instead of links (zero-padded taps, self pairs)
+      uint32_t zm = r0.x, sm = r0.y;
+      if (M == NFP_COSINE) {
+        while (sm) {  // (p, n) with q == p: both ends of the pair are r
+          const int n = __builtin_ctz(sm);
+          sm &= sm - 1;
+          const float2 v = AD[n * P + r];
+          S += 2.f * v.x;
+          Dj += 2.f * v.y;
         }
-        Out[p * K2 + j] = o;
-        Osq[p * K2 + j] = q2;
-        if (j == K2 / 2) {
-          const float4* pa = (const float4*)(SP + p * N);
-          float sps = 0.f;
-#pragma unroll
-          for (int m = 0; m < N / 4; ++m) {
-            const float4 v4 = pa[m];
-            sps += (v4.x + v4.y) + (v4.z + v4.w);
-          }
-          SPs[p] = sps;
+        wv = ipn[r] * ipn[r] * S;
+      } else {
+        uint32_t m = g.diff ? zm : sm;  // diff: |x_p - 0| still pulls on x_p; quirk: |x_q| with q == p
+        while (m) {
+          const int n = __builtin_ctz(m);
+          m &= m - 1;
+          Dj += CC[n * P + r];
         }
+        wv = 0.f;
       }
     }
-    __syncthreads();
-    NFP_STAMP(3);
-    if (active) {
-      for (int j = gl; j < K2; j += g.G) {
-        const int jy = j / K, jx = j - jy * K;
-        const int ty = py + jy - R, tx = px + jx - R;
-        float wv = 0.f;
-        if (ty >= 0 && ty < g.H && tx >= 0 && tx < g.W) {
-          wv = Out[p * K2 + j] + Out[(ty * g.W + tx) * K2 + (K2 - 1 - j)];
-          if (j == K2 / 2) {
-            wv += SPs[p];
-#pragma unroll
-            for (int jj = 0; jj < K2; ++jj) {
-              const int uy = py + jj / K - R, ux = px + jj % K - R;
-              if (uy >= 0 && uy < g.H && ux >= 0 && ux < g.W) wv += Osq[(uy * g.W + ux) * K2 + (K2 - 1 - jj)];
-            }
-          }
-        }
-        Wt[p * K2 + j] = wv;
-      }
-    }
-    __syncthreads();
-    NFP_STAMP(4);
+    Wt[e] = wv;
+    Dt[e] = Dj;
   }
+  // (the pair values stay readable until the barrier: with g.early the slab does not overlap them, so the x chunk
+  // is committed here, while slower wavefronts still gather)
+  if constexpr (!GEMM) {
+    if (g.early) {
+#pragma unroll
+      for (int part = 0; part < kRB; ++part)
+        stage_commit<BF, NHWC>(st, slab, g, min(g.Cc, cb1 - cb0) >> 2, t, T, p, gl, active, part);
+    }
+  }
+  __syncthreads();
+  NFP_STAMP(3);
+  if constexpr (FOLD_PHASE) {
+    // A3: the diagonal — every pair that contains r pulls on x_r itself — folded in a fixed order
+    for (int r = t; r < P; r += T) {
+      float s = Wt[r * K2 + K2 / 2];
+      const float fac = M == NFP_COSINE ? dfn[r] : 1.f;
+#pragma unroll
+      for (int j = 0; j < K2; ++j) s = fmaf(fac, Dt[r * K2 + j], s);
+      Wt[r * K2 + K2 / 2] = s;
+    }
+    __syncthreads();
+  }
+  NFP_STAMP(4);
   if constexpr (GEMM) {
-    // (the coefficient tables behind Wt are dead: their LDS becomes the GEMM's operand images)
-    bwd_gemm_phase<R, NHWC>(g, Wt, (uint4*)slab, (const uint16_t*)x + (long long)b * g.sB,
+    // (the pair values behind the tables are dead: their LDS becomes the GEMM's operand images)
+    bwd_gemm_phase<R, NHWC>(g, Wt, (uint4*)pv4, (const uint16_t*)x + (long long)b * g.sB,
                             (uint16_t*)gx + (long long)b * g.gB, cb0, cb1, t, T);
     return;
   }
   float w[K2];
   int off[K2];
+  {
+    float dsum = 0.f;
 #pragma unroll
-  for (int j = 0; j < K2; ++j) {
-    const int dy = j / K - R, dx = j % K - R;
-    const bool ok = py + dy >= 0 && py + dy < g.H && px + dx >= 0 && px + dx < g.W;
-    off[j] = ok ? swz(p + dy * g.W + dx) - swz(p) : 0;
-    w[j] = ok ? Wt[p * K2 + j] : 0.f;
+    for (int j = 0; j < K2; ++j) {
+      const uint32_t wd = j & 1 ? ((const uint32_t*)bo)[j >> 1] >> 16 : ((const uint32_t*)bo)[j >> 1] & 0xFFFFu;
+      off[j] = (int)(int16_t)wd;              // 0 for a slot outside the image ...
+      w[j] = active ? Wt[p * K2 + j] : 0.f;   // ... whose weight phase A left at 0
+      if constexpr (!FOLD_PHASE) dsum += active ? Dt[p * K2 + j] : 0.f;
+    }
+    if constexpr (!FOLD_PHASE) w[K2 / 2] = fmaf(M == NFP_COSINE ? dfn[active ? p : 0] : 1.f, dsum, w[K2 / 2]);
   }
   // B: one pass over the channel block; results leave straight from registers with write-through
   // (sc1) stores — 4 dwords per slot for NCHW, one 16-byte store for channels-last — so grad_x
@@ -923,9 +827,11 @@ __global__ void __launch_bounds__(GEMM ? 1024 : kBwdThreads) bwd_fast(const KP g
       __syncthreads();
       stage_issue<BF, NHWC>(st, xb, g, c0, ncq, t, T, p, gl, active);
     }
+    if (c0 > cb0 || !g.early) {
 #pragma unroll
-    for (int part = 0; part < kRB; ++part) stage_commit<BF, NHWC>(st, slab, g, ncq, t, T, p, gl, active, part);
-    __syncthreads();
+      for (int part = 0; part < kRB; ++part) stage_commit<BF, NHWC>(st, slab, g, ncq, t, T, p, gl, active, part);
+      __syncthreads();
+    }
     NFP_STAMP(5);
     if (active) {
 #pragma unroll NFP_UNROLL_B

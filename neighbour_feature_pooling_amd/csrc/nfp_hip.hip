@@ -12,6 +12,7 @@
 #include <cstring>
 #include <mutex>
 #include <unordered_map>
+#include <vector>
 
 #include <cstdlib>
 
@@ -122,6 +123,7 @@ int make_kp(const nfp_desc* d, KP* g) {
   g->p = d->p; g->eps = d->eps; g->q_scs = d->q_scs;
   g->sB = d->sxB; g->sC = d->sxC; g->sH = d->sxH; g->sW = d->sxW;
   g->gB = d->sgB != 0 ? d->sgB : d->sxB;
+  g->ws = (const unsigned char*)d->ws;
   g->contig = (d->sxW == 1 && d->sxH == d->W && d->sxC == (int64_t)d->H * d->W) ? 1 : 0;
   g->invP = 1.0f / (float)g->P;
   g->invW = 1.0f / (float)g->W;
@@ -182,7 +184,7 @@ int launch(const char* name, K kernel, dim3 grid, dim3 block, size_t lds, hipStr
   }
   if (int rc = set_lds(kernel, lds)) return rc;
   hipLaunchKernelGGL(kernel, grid, block, lds, st, args...);
-  g_launches++;
+  if (name[0] != '#') g_launches++;  // ('#': one-time setup kernels, not part of a forward / backward)
   return hip_ok(hipGetLastError(), name);
 }
 
@@ -461,12 +463,18 @@ constexpr int kSlabBudgetBwd = NFP_BWD_SLAB_KB * 1024;
 
 bool force_generic() { return g_sw.force_generic.load(std::memory_order_relaxed) != 0; }
 
+// Geometry of the hot path: "same" maps (stride 1, dilation 1, pad = R) small enough for one workgroup per image.
+// These are the descriptors that have workspace tables (nfp_tables.h).
+bool fast_geometry(const KP& g) {
+  if (g.stride != 1 || g.dil != 1 || g.pad != g.R || g.mode == NFP_PAD_CIRCULAR) return false;
+  if (g.R != 1 && g.R != 2) return false;
+  return g.P <= kBwdThreads && g.P >= 4;
+}
+
 // Which calls the hot-path kernels serve; everything else runs on the generic kernels.
 bool fast_ok(const KP& g, const void* x, const void* gx) {
   if (force_generic()) return false;
-  if (g.stride != 1 || g.dil != 1 || g.pad != g.R || g.mode == NFP_PAD_CIRCULAR) return false;
-  if (g.R != 1 && g.R != 2) return false;
-  if ((g.C & 3) || g.P > kBwdThreads || g.P < 4) return false;
+  if (!fast_geometry(g) || (g.C & 3)) return false;
   if (!(g.measure == NFP_COSINE || (g.measure == NFP_NORM && g.p == 2.f))) return false;
   const bool nhwc = g.sC == 1 && g.sW == g.C && g.sH == (long long)g.W * g.C;
   if (!g.contig && !nhwc) return false;
@@ -543,6 +551,14 @@ int launch_fwd_fast(const KP& g, const void* x, void* out, float* saved, hipStre
               : launch_fwd_fast_t<R, M, false, false>(g, x, out, saved, st);
 }
 
+// LDS of bwd_fast's phase A: tables that live to the end of the kernel (Wt, Dt, two norm factors per pixel), and
+// the per-pair values, which are dead once Wt is built (nfp_fast.h::bwd_fast)
+size_t bwd_fixed_bytes(const KP& g, int K2) { return ((size_t)(2 * g.P * K2 + 2 * g.P) * 4 + 15) & ~(size_t)15; }
+size_t bwd_pair_bytes(const KP& g, int M, int N) {
+  return ((size_t)((M == NFP_COSINE ? 2 : 1) * N * g.P) * 4 + 15) & ~(size_t)15;
+}
+constexpr size_t kEarlyBudget = 96 * 1024;  // slab beside the pair values (committed during phase A) up to this much LDS
+
 template <int R, int M, bool BF, bool NHWC, bool POOL = false>
 int launch_bwd_fast_t(KP g, const void* x, const void* go, const void* out, const float* saved, void* gx,
                       hipStream_t st, const float* ggap = nullptr, const float* gnfpm = nullptr) {
@@ -565,16 +581,15 @@ int launch_bwd_fast_t(KP g, const void* x, const void* go, const void* out, cons
   g.G = even_groups(g.Cc / 4, g.G);
   T = ((g.P * g.G + 63) / 64) * 64;
   g.Cc = chunk_channels(g, g.Cwg, T, g.G, NHWC, bbudget);
-  size_t wt = (size_t)g.P * K2 * 4;
-  size_t tables = (size_t)(4 * g.P * N + g.P * K2 + (R >= 2 ? 2 * g.P * K2 + g.P : 0)) * 4;  // Qt CR SP SQ Sq2 [Out Osq SPs]
-  size_t slab = (size_t)(g.Cc / 4) * ((g.P + 3) & ~3) * 16;
-  size_t xs = slab > tables ? slab : tables;
-  size_t lds = ((wt + 15) & ~(size_t)15) + xs;
+  const size_t fixed = bwd_fixed_bytes(g, K2), pairs = bwd_pair_bytes(g, M, N);
+  const size_t slab = (size_t)(g.Cc / 4) * ((g.P + 3) & ~3) * 16;
+  g.early = fixed + pairs + slab <= kEarlyBudget ? 1 : 0;
+  const size_t lds = g.early ? fixed + pairs + slab : fixed + std::max(pairs, slab);
   if (lds > (size_t)kLdsMax) return kNotApplicable;  // tables + slab do not fit: the generic kernels serve it
   snprintf(g_variant, sizeof(g_variant), "bwd_fast<R%d,%s,%s,%s%s>", R, M == NFP_COSINE ? "cos" : "l2",
            BF ? "bf16" : "f32", NHWC ? "nhwc" : "nchw", POOL ? ",pool" : "");
   return launch("bwd_fast", bwd_fast<R, M, BF, NHWC, POOL>, dim3(g.B, S), dim3(T), lds, st, g, x, go, out, saved, gx,
-                ggap, gnfpm);
+                ggap, gnfpm, g.ws);
 }
 
 // Matrix-core forward (nfp_mfma.h): bf16, dense channels-last, C a multiple of 16.
@@ -623,15 +638,14 @@ int launch_bwd_gemm_t(KP g, const void* x, const void* go, const void* out, cons
   g.Cc = g.Cwg;
   const int band = g.R * g.W + g.R, KW = (32 + 2 * band + 30) >> 4;
   const size_t xq = (size_t)((((g.P + 15) >> 4 << 1) + 1) | 1), wq = (size_t)((2 * KW + 1) | 1);
-  const size_t wt = (size_t)g.P * K2 * 4;
-  const size_t tables = (size_t)(4 * g.P * N + g.P * K2 + (R >= 2 ? 2 * g.P * K2 + g.P : 0)) * 4;
   const size_t images = ((size_t)g.Cwg * xq + 2 * 2 * 32 * wq) * 16;
-  const size_t lds = ((wt + 15) & ~(size_t)15) + std::max(tables, images);
+  const size_t lds = bwd_fixed_bytes(g, K2) + std::max(bwd_pair_bytes(g, M, N), images);
+  g.early = 0;
   if (lds > (size_t)kLdsMax) return kNotApplicable;
   snprintf(g_variant, sizeof(g_variant), "bwd_fast<R%d,%s,bf16,%s,mfma>", R, M == NFP_COSINE ? "cos" : "l2",
            NHWC ? "nhwc" : "nchw");
   return launch("bwd_fast_mfma", bwd_fast<R, M, true, NHWC, false, true>, dim3(g.B, S), dim3(T), lds, st, g, x, go, out,
-                saved, gx, (const float*)nullptr, (const float*)nullptr);
+                saved, gx, (const float*)nullptr, (const float*)nullptr, g.ws);
 }
 
 template <int R, int M>
@@ -768,7 +782,7 @@ int backward_impl(const nfp_desc* d, const void* x, const void* grad_out, const 
   if ((stats_of(g.measure) > 0 || g.measure == NFP_ATTENTION) && !saved) return fail(NFP_E_INVALID, "measure %d needs the saved state of nfp_forward", g.measure);
   if (g.B == 0) return NFP_OK;
   hipStream_t st = (hipStream_t)hip_stream;
-  if (fast_ok(g, x, grad_x)) {
+  if (g.ws != nullptr && fast_ok(g, x, grad_x)) {
     int rc;
     if (g.measure == NFP_COSINE)
       rc = g.R == 1 ? launch_bwd_fast<1, NFP_COSINE>(g, x, grad_out, out, saved, grad_x, st)
@@ -817,6 +831,63 @@ int backward_impl(const nfp_desc* d, const void* x, const void* grad_out, const 
 
 extern "C" {
 
+// Exact maximum number of (pixel, tap) pairs linking two pixels, by enumeration on the host: the link rows of the
+// workspace have the fixed width ws_link_width(); a geometry that would overflow it gets no tables.
+static int max_links(const KP& g) {
+  auto fold = [&](int v, int n) {
+    const bool lo = v < 0, hi = v >= n;
+    if (!lo && !hi) return v;
+    if (g.mode == NFP_PAD_REFLECT) return lo ? -v : 2 * (n - 1) - v;
+    if (g.mode == NFP_PAD_REPLICATE) return lo ? 0 : n - 1;
+    return -1;
+  };
+  const int K = g.k, R = g.R;
+  // per axis: cnt[a][b] = taps d in [-R, R] with fold(a + d) == b
+  auto axis = [&](int n, std::vector<int>& cnt) {
+    cnt.assign((size_t)n * n, 0);
+    for (int a = 0; a < n; ++a)
+      for (int dd = -R; dd <= R; ++dd) {
+        const int f = fold(a + dd, n);
+        if (f >= 0) cnt[(size_t)a * n + f]++;
+      }
+  };
+  std::vector<int> cy, cx;
+  axis(g.H, cy);
+  axis(g.W, cx);
+  int best = 0;
+  for (int ry = 0; ry < g.H; ++ry)
+    for (int ty = std::max(0, ry - R); ty <= std::min(g.H - 1, ry + R); ++ty)
+      for (int rx = 0; rx < g.W; ++rx)
+        for (int tx = std::max(0, rx - R); tx <= std::min(g.W - 1, rx + R); ++tx) {
+          if (ry == ty && rx == tx) continue;
+          const int a = cy[(size_t)ry * g.H + ty] * cx[(size_t)rx * g.W + tx];  // taps of r that read t
+          const int b = cy[(size_t)ty * g.H + ry] * cx[(size_t)tx * g.W + rx];  // taps of t that read r
+          best = std::max(best, a + b);
+        }
+  (void)K;
+  return best;
+}
+
+int64_t nfp_workspace_bytes(const nfp_desc* d) {
+  KP g;
+  if (make_kp(d, &g)) return -1;
+  if (!fast_geometry(g)) return 0;
+  const WsLayout L = ws_layout(g.P, g.R, g.mode);
+  if (max_links(g) > L.LW) return 0;
+  return (int64_t)L.bytes;
+}
+
+int nfp_workspace_init(const nfp_desc* d, void* ws, void* hip_stream) {
+  KP g;
+  if (int rc = make_kp(d, &g)) return rc;
+  if (nfp_workspace_bytes(d) <= 0) return fail(NFP_E_UNSUPPORTED, "this descriptor has no workspace tables");
+  if (!ws || ((uintptr_t)ws & 15)) return fail(NFP_E_INVALID, "workspace pointer must be non-null and 16-byte aligned");
+  hipStream_t st = (hipStream_t)hip_stream;
+  const int items = g.P * g.k * g.k, blocks = std::min(64, (items + 255) / 256);
+  return g.R == 1 ? launch("#fill_workspace", fill_workspace<1>, dim3(blocks), dim3(256), 0, st, g, (unsigned char*)ws)
+                  : launch("#fill_workspace", fill_workspace<2>, dim3(blocks), dim3(256), 0, st, g, (unsigned char*)ws);
+}
+
 int nfp_forward(const nfp_desc* d, const void* x, void* out, float* saved, void* hip_stream) {
   return finish(forward_impl(d, x, out, saved, hip_stream), "nfp_forward");
 }
@@ -835,6 +906,9 @@ int nfp_plan(const nfp_desc* d, int32_t backward, char* buf, int32_t buflen) {
   t_dry = true;  // (thread-local, like the variant and plan buffers: concurrent calls do not see each other)
   t_plan[0] = 0;
   void* fake = (void*)(uintptr_t)0x1000;
+  nfp_desc dd = *d;  // as the caller would run it: with the workspace the descriptor is entitled to
+  if (dd.ws == nullptr && nfp_workspace_bytes(&dd) > 0) dd.ws = fake;
+  d = &dd;
   const int rc = finish(backward ? backward_impl(d, fake, fake, fake, (const float*)fake, fake, nullptr)
                                  : forward_impl(d, fake, fake, (float*)fake, nullptr),
                         "nfp_plan");
@@ -849,9 +923,10 @@ int nfp_pool_supported(const nfp_desc* d) {
   if (make_kp(d, &g)) return 0;
   // hot-path geometry, NCHW float32 (x pointer alignment does not matter for NCHW), tables must fit LDS
   if (!(g.dtype == NFP_F32 && g.contig && fast_ok(g, nullptr, nullptr))) return 0;
+  if (g.ws == nullptr) return 0;  // the backward reads its index maps from the workspace
   const int K2 = g.k * g.k;
-  const size_t bwd_tables = (size_t)g.P * K2 * 4 + (size_t)(4 * g.P * g.N + g.P * K2 + (g.R >= 2 ? 2 * g.P * K2 + g.P : 0)) * 4;
-  return bwd_tables + 64 <= (size_t)kLdsMax ? 1 : 0;  // the x slab shares the tables' region (they are dead by then)
+  const size_t bwd_tables = bwd_fixed_bytes(g, K2) + bwd_pair_bytes(g, g.measure, g.N);
+  return bwd_tables + 64 <= (size_t)kLdsMax ? 1 : 0;  // the x slab shares the pair values' region (dead by then)
 }
 
 int nfp_pool_forward(const nfp_desc* d, const void* x, float* gap, float* nfpm, void* out_map, float* saved,
@@ -859,7 +934,8 @@ int nfp_pool_forward(const nfp_desc* d, const void* x, float* gap, float* nfpm, 
   KP g;
   if (int rc = make_kp(d, &g)) return rc;
   if (!x || !gap || !nfpm || !out_map) return fail(NFP_E_INVALID, "null tensor pointer");
-  if (!nfp_pool_supported(d)) return fail(NFP_E_UNSUPPORTED, "fused pooling tail: hot-path geometry, NCHW float32 only");
+  if (!nfp_pool_supported(d))
+    return fail(NFP_E_UNSUPPORTED, "fused pooling tail: hot-path geometry, NCHW float32, descriptor with a workspace only");
   if (g.B == 0) return NFP_OK;
   hipStream_t st = (hipStream_t)hip_stream;
   int rc;
@@ -877,7 +953,8 @@ int nfp_pool_backward(const nfp_desc* d, const void* x, const float* grad_gap, c
   KP g;
   if (int rc = make_kp(d, &g)) return rc;
   if (!x || !grad_gap || !grad_nfpm || !out_map || !grad_x) return fail(NFP_E_INVALID, "null tensor pointer");
-  if (!nfp_pool_supported(d)) return fail(NFP_E_UNSUPPORTED, "fused pooling tail: hot-path geometry, NCHW float32 only");
+  if (!nfp_pool_supported(d))
+    return fail(NFP_E_UNSUPPORTED, "fused pooling tail: hot-path geometry, NCHW float32, descriptor with a workspace only");
   if (stats_of(g.measure) > 0 && !saved) return fail(NFP_E_INVALID, "missing saved state");
   if (g.B == 0) return NFP_OK;
   hipStream_t st = (hipStream_t)hip_stream;

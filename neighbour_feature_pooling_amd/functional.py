@@ -101,6 +101,32 @@ def output_shape(d):
     return d.B, n.value, ho.value, wo.value
 
 
+_WORKSPACES = {}            # (device, geometry) -> uint8 tensor: the descriptor's constant tables, built once
+
+
+def _workspace(d, device):
+    """Device pointer of the constant tables of `d` (include/nfp.h: nfp_workspace_bytes / nfp_workspace_init), or
+    None.  They depend on the geometry only, so every call with the same map size and kernel shares one buffer per
+    device; the fill kernel is enqueued once, on the current stream (allocations made under a side stream or a graph
+    capture stay valid for later streams: the buffer is never freed while it is cached)."""
+    key = (device.index, d.H, d.W, d.R, d.pad, d.stride, d.dilation, d.pad_mode)
+    ws = _WORKSPACES.get(key)
+    if ws is None:
+        L = _abi.load()
+        nbytes = int(L.nfp_workspace_bytes(ctypes.byref(d)))
+        if nbytes <= 0:
+            _WORKSPACES[key] = ws = False
+        else:
+            with _on_device(device):
+                ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+                _abi.check(L.nfp_workspace_init(ctypes.byref(d), ws.data_ptr(), _raw_stream(device)))
+                # the tables are read by later launches on ANY stream: make the fill visible to all of them once
+                if not torch.cuda.is_current_stream_capturing():
+                    torch.cuda.current_stream(device).synchronize()
+            _WORKSPACES[key] = ws
+    return ws.data_ptr() if ws is not False else None
+
+
 _PLANS = OrderedDict()      # least recently used first
 _PLANS_MAX = 256
 
@@ -124,11 +150,12 @@ def _plan(x, layout, cfg):
     entry is None when nfp_backward serves the descriptor too, else the library's message: forward and backward
     envelopes differ for a few large maps, and a call that will need a gradient must fail in forward(), not inside
     loss.backward()."""
-    key = (tuple(x.shape), x.stride(0), layout, x.dtype, cfg)
+    key = (tuple(x.shape), x.stride(0), layout, x.dtype, cfg, x.device.index)
     plan = _plans_get(key)
     if plan is None:
         L = _abi.load()
         d = make_desc(x, cfg, layout)
+        d.ws = _workspace(d, x.device)
         buf = ctypes.create_string_buffer(1024)
         rc = L.nfp_plan(ctypes.byref(d), 1, buf, len(buf))
         no_bwd = None if rc == 0 else L.nfp_last_error().decode()
@@ -246,10 +273,10 @@ def nfp_pool_fused_ok(x, cfg):
     """True when the fused GAP + pooled-NFP kernels can serve this call (hot-path geometry, NCHW f32)."""
     if not (x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and x.is_contiguous()):
         return False
-    key = ("pool", tuple(x.shape), cfg)
+    key = ("pool", tuple(x.shape), cfg, x.device.index)
     ok = _plans_get(key)
     if ok is None:
-        ok = bool(_abi.load().nfp_pool_supported(ctypes.byref(make_desc(x, cfg, "nchw"))))
+        ok = bool(_abi.load().nfp_pool_supported(ctypes.byref(_plan(x, "nchw", cfg)[0])))
         _plans_put(key, ok)
     return ok
 

@@ -38,10 +38,11 @@ def test_abi_version_matches_header(lib):
 
 
 def test_desc_layout_matches_header():
-    # 13 int32 + 3 float + 5 int64, naturally aligned
-    assert ctypes.sizeof(_abi.NfpDesc) == 13 * 4 + 3 * 4 + 5 * 8
+    # 13 int32 + 3 float + 5 int64 + 1 pointer, naturally aligned
+    assert ctypes.sizeof(_abi.NfpDesc) == 13 * 4 + 3 * 4 + 5 * 8 + 8
     assert _abi.NfpDesc.sxB.offset == 64
     assert _abi.NfpDesc.sgB.offset == 96
+    assert _abi.NfpDesc.ws.offset == 104
 
 
 def _desc(shape, R=1, pad=1, stride=1, dil=1, mode="reflect", measure="cosine"):
@@ -162,3 +163,20 @@ def test_env_switches_take_effect_only_through_reload(lib, monkeypatch):
     monkeypatch.delenv("NFP_FORCE_GENERIC")
     lib.nfp_reload_env()
     assert lib.nfp_plan(ctypes.byref(d), 0, buf, len(buf)) == 0 and buf.value.startswith(b"fwd_fast")
+
+
+def test_workspace_bytes(lib):
+    """Constant tables exist for the hot-path geometry (stride 1, pad = R, R <= 2, map <= 512 pixels) only."""
+    assert lib.nfp_workspace_bytes(ctypes.byref(_desc((64, 512, 7, 7)))) > 0
+    assert lib.nfp_workspace_bytes(ctypes.byref(_desc((4, 192, 14, 14), R=2, pad=2, measure="norm"))) > 0
+    assert lib.nfp_workspace_bytes(ctypes.byref(_desc((4, 192, 14, 14), R=2, pad=2, mode="replicate"))) > 0
+    assert lib.nfp_workspace_bytes(ctypes.byref(_desc((2, 16, 9, 9), stride=2))) == 0
+    assert lib.nfp_workspace_bytes(ctypes.byref(_desc((2, 16, 9, 9), pad=0))) == 0
+    assert lib.nfp_workspace_bytes(ctypes.byref(_desc((2, 16, 40, 40)))) == 0
+    assert lib.nfp_workspace_bytes(ctypes.byref(_desc((2, 16, 9, 9), mode="circular"))) == 0
+    assert lib.nfp_workspace_bytes(ctypes.byref(_desc((1, 0, 5, 5)))) == -1
+    # the same tables whatever B, C, measure: one buffer per geometry
+    a = lib.nfp_workspace_bytes(ctypes.byref(_desc((1, 8, 7, 7))))
+    assert a == lib.nfp_workspace_bytes(ctypes.byref(_desc((64, 512, 7, 7), measure="norm")))
+    d = _desc((64, 512, 7, 7))
+    assert lib.nfp_workspace_init(ctypes.byref(d), None, None) == -1
