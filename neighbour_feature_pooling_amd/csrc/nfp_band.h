@@ -1,0 +1,213 @@
+// nfp_band.h — the hot-path forward, split into ROW BANDS of an image (replaces nfp.py:132-159 like fwd_fast).
+//
+// Why: at the headline shape [64,512,7,7] one workgroup per image puts 64 workgroups on 256 compute units and each
+// of them ingests 100 KB and sums 512 channels alone (round 1: 3 us of a 6.2 us workgroup).  Here workgroup
+// (image b, band j) OWNS output rows [j*rb, (j+1)*rb) and stages those rows plus the R rows below them; with the
+// half stencil a pair (p, q = p + forward direction) is summed by the band that owns p, so no band needs rows above
+// its own and nothing is combined across workgroups.  Every output (n, p) is WRITTEN by the band that owns the
+// forward end of its pair (table `ft`, nfp_tables.h) — for the R rows below a band that is the band above — so each
+// element of `out` has exactly one writer, no atomics, and a launch is bitwise reproducible.  (The number of bands
+// follows the batch size, and with it the number of channel groups a pixel's sums are split into: results for
+// different batch sizes agree to float32 rounding, not bitwise.)  At B >= 256 the launcher asks for one band = the
+// whole image.
+//
+// LDS slab layout, staging blocks and the pixel-slot rotation are those of nfp_fast.h, with slots counted from the
+// band's first staged pixel rounded down to a multiple of 8 (so that the rotation, and with it the offset table
+// `foff`, is the same as for the whole image).
+#pragma once
+#include "nfp_fast.h"
+
+namespace nfp {
+
+constexpr int kBandT = 512;  // threads per workgroup
+constexpr int kBandRB = 3;   // NCHW staging: 4-pixel x 4-channel blocks per thread per chunk
+constexpr int kBandRN = 6;   // channels-last staging: slots per thread per chunk
+
+template <int R>
+struct FoffQ {
+  static constexpr int v = ((Win<R>::NF + 7) & ~7) / 8;  // 16-byte pieces of a pixel's foff row (ws_layout: FR)
+};
+
+template <int R, int M, bool BF, bool NHWC>
+__global__ void __launch_bounds__(kBandT) fwd_band(const KP g, const void* __restrict__ x, void* __restrict__ out,
+                                                   float* __restrict__ saved, const unsigned char* __restrict__ ws,
+                                                   int rb) {
+  constexpr int N = Win<R>::N, NF = Win<R>::NF;
+  constexpr int ES = BF ? 2 : 4;
+  extern __shared__ __attribute__((aligned(16))) float4 lds4[];
+  float4* slab = lds4;
+  const int P = g.P, W = g.W;
+  const int b = blockIdx.x, band = blockIdx.y, t = threadIdx.x;
+  constexpr int T = kBandT;
+  // rows: owned [y0, y1), staged [y0, ye); pixels: owned [p0, po), staged [p0, pe)
+  const int y0 = band * rb, y1 = min(g.H, y0 + rb), ye = min(g.H, y1 + R);
+  const int p0 = y0 * W, po = y1 * W, pe = ye * W, Ps = pe - p0;
+  const int base = p0 & ~7;                      // slot origin of the band's slab rows
+  const int Ppb = ((pe + 3) & ~3) - base;        // slots per slab row (one channel quad)
+  const int G = min(fdivi(T, Ps), g.C >> 2);     // channel groups: thread (lp, gl) owns quads gl, gl + G, ...
+  const int gl = fdivi(t, Ps), lp = t - gl * Ps, p = p0 + lp;
+  const bool active = gl < G;
+  const Rsrc xb = make_rsrc((const char*)x + (long long)b * g.sB * ES, (long long)g.C * P * ES);  // wave-uniform
+  const WsLayout L = ws_layout(P, R, g.mode);
+
+  NFP_STAMP_INIT();
+  NFP_STAMP(0);
+  // ---- tables first (small, shared by every workgroup: L2), then the x chunk ---------------------------------
+  const uint32_t* ftt = (const uint32_t*)(ws + L.ft);
+  uint32_t fte = ftt[min(gl, N - 1) * P + p];     // this thread's first output (n = gl, p)
+  uint4 fo[FoffQ<R>::v];
+  {
+    const uint4* fot = (const uint4*)(ws + L.foff) + (long long)p * FoffQ<R>::v;
+#pragma unroll
+    for (int u = 0; u < FoffQ<R>::v; ++u) fo[u] = fot[u];
+  }
+  __builtin_amdgcn_sched_barrier(0);
+
+  // NCHW blocks of the band: 4-pixel blocks q0 .. q1-1 of every channel; the last block of an image whose pixel
+  // count is not a multiple of 4 starts at P - 4 instead (it overlaps its predecessor: same values, written twice)
+  const int q0 = p0 >> 2, q1 = (pe + 3) >> 2, NQb = q1 - q0;
+  float4 blk[kBandRB][4];
+  float4 nv[kBandRN];
+  auto issue = [&](int c0, int ncq) {
+    if constexpr (NHWC) {
+      const int g0 = active ? gl : 0;
+      const int last = g0 < ncq ? g0 + fdivi(ncq - 1 - g0, G) * G : 0;
+#pragma unroll
+      for (int k = 0; k < kBandRN; ++k) {
+        const int cq = min(g0 + k * G, last);
+        nv[k] = load_px4<BF>(xb, p * g.C + c0 + 4 * cq, 0);
+      }
+    } else {
+      const int nblk = ncq * NQb;
+#pragma unroll
+      for (int r = 0; r < kBandRB; ++r) {
+        const int i = min(t + r * T, nblk - 1);
+        const int cq = fdivi(i, NQb), pq = q0 + i - cq * NQb;
+        const int e = (c0 + 4 * cq) * P + min(4 * pq, P - 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) blk[r][j] = load_px4<BF>(xb, e, j * P);
+      }
+    }
+  };
+  auto commit = [&](int ncq) {
+    if constexpr (NHWC) {
+#pragma unroll
+      for (int k = 0; k < kBandRN; ++k) {
+        const int cq = gl + k * G;
+        if (active && cq < ncq) slab[cq * Ppb + swz(p) - base] = nv[k];
+      }
+    } else {
+      const int nblk = ncq * NQb;
+#pragma unroll
+      for (int r = 0; r < kBandRB; ++r) {
+        const int i = t + r * T;
+        if (i < nblk) {
+          const int cq = fdivi(i, NQb), pq = q0 + i - cq * NQb;
+          const int ps = min(4 * pq, P - 4);
+          float4* d = slab + cq * Ppb - base;
+          d[swz(ps)] = make_float4(blk[r][0].x, blk[r][1].x, blk[r][2].x, blk[r][3].x);
+          d[swz(ps + 1)] = make_float4(blk[r][0].y, blk[r][1].y, blk[r][2].y, blk[r][3].y);
+          d[swz(ps + 2)] = make_float4(blk[r][0].z, blk[r][1].z, blk[r][2].z, blk[r][3].z);
+          d[swz(ps + 3)] = make_float4(blk[r][0].w, blk[r][1].w, blk[r][2].w, blk[r][3].w);
+        }
+      }
+    }
+  };
+  issue(0, min(g.Cc, g.C) >> 2);
+  __builtin_amdgcn_sched_barrier(0);
+  NFP_STAMP(1);
+
+  int off[NF];
+#pragma unroll
+  for (int d = 0; d < NF; ++d) {
+    const uint32_t wd = d & 1 ? ((const uint32_t*)fo)[d >> 1] >> 16 : ((const uint32_t*)fo)[d >> 1] & 0xFFFFu;
+    off[d] = p < po ? (int)(int16_t)wd : 0;   // halo pixels only need their norm: their pairs belong to the next band
+  }
+  float acc[NF];
+#pragma unroll
+  for (int d = 0; d < NF; ++d) acc[d] = 0.f;
+  float nrm = 0.f;
+  const int sp = swz(p) - base;
+
+  for (int c0 = 0; c0 < g.C; c0 += g.Cc) {
+    const int ncq = min(g.Cc, g.C - c0) >> 2;
+    if (c0 > 0) {
+      __syncthreads();  // previous chunk fully consumed
+      issue(c0, ncq);
+    }
+    commit(ncq);
+    __syncthreads();
+    if (c0 == 0) NFP_STAMP(2);
+    if (active) {
+      for (int cq = gl; cq < ncq; cq += G) {
+        const float4* row = slab + cq * Ppb + sp;
+        const float4 a = row[0];
+        nrm = fmaf(a.x, a.x, fmaf(a.y, a.y, fmaf(a.z, a.z, fmaf(a.w, a.w, nrm))));
+#pragma unroll
+        for (int d = 0; d < NF; ++d) {
+          const float4 q = row[off[d]];
+          if (M == NFP_COSINE) {
+            acc[d] = fmaf(a.x, q.x, fmaf(a.y, q.y, fmaf(a.z, q.z, fmaf(a.w, q.w, acc[d]))));
+          } else {
+            const float e0 = a.x - q.x, e1 = a.y - q.y, e2 = a.z - q.z, e3 = a.w - q.w;
+            acc[d] = fmaf(e0, e0, fmaf(e1, e1, fmaf(e2, e2, fmaf(e3, e3, acc[d]))));
+          }
+        }
+      }
+    }
+  }
+  // ---- channel-group reduction through LDS, fixed order -------------------------------------------------------
+  __syncthreads();
+  NFP_STAMP(3);
+  float* red = (float*)lds4;              // [G][NF+1][Ps]
+  const int NV = (NF + 1) * Ps;
+  float* Tt = red + G * NV;               // [NF+1][Ps]: pair sums per forward direction, then |x|^2
+  if (active) {
+#pragma unroll
+    for (int d = 0; d < NF; ++d) red[gl * NV + d * Ps + lp] = acc[d];
+    red[gl * NV + NF * Ps + lp] = nrm;
+  }
+  __syncthreads();
+  for (int i = t; i < NV; i += T) {
+    float s = 0.f;
+    for (int gg = 0; gg < G; ++gg) s += red[gg * NV + i];
+    Tt[i] = s;
+  }
+  __syncthreads();
+  NFP_STAMP(4);
+  // ---- outputs (n, p) whose pair this band summed: thread (lp, n = gl, gl + G', ...) -------------------------
+  const float* n2 = Tt + NF * Ps;
+  const int Gn = fdivi(T, Ps);            // (all thread groups take part, not only the G that had channels)
+  if (gl < Gn) {
+    void* ob = (char*)out + (long long)b * N * P * ES;
+    const float n2p = n2[lp];
+    const float ip = inv_norm(n2p, g.inv_eps);
+    for (int n = gl; n < N; n += Gn) {
+      const uint32_t e = n == gl ? fte : ftt[n * P + p];
+      const int kind = (int)(e >> 22), pix = (int)((e >> 9) & 511u), fi = (int)((e >> 18) & 15u);
+      const int q = kind == 2 ? p : (int)(e & 511u);
+      if (pix >= p0 && pix < po) {
+        const float pairv = Tt[fi * Ps + pix - p0];
+        const float n2q = n2[q - p0];
+        float v;
+        if (M == NFP_COSINE) {
+          const float s = kind == 2 ? 0.f : (kind == 1 ? n2p : pairv) * ip * inv_norm(n2q, g.inv_eps);
+          v = g.similarity ? s : 1.f - s;
+        } else {
+          float d2;
+          if (g.diff)
+            d2 = kind == 2 ? n2p : (kind == 1 ? 0.f : pairv);
+          else
+            d2 = kind == 2 ? 0.f : n2q;  // 'Norm' quirk (nfp.py:74 vs 85): |neighbour|
+          const float dd = __builtin_amdgcn_sqrtf(d2);
+          v = g.similarity ? -dd : dd;
+        }
+        stx(ob, n * P + p, v, BF ? NFP_BF16 : NFP_F32);
+      }
+    }
+    if (M == NFP_COSINE && saved != nullptr && gl == 0 && p < po) saved[(long long)b * P + p] = __builtin_amdgcn_sqrtf(n2p);
+  }
+  NFP_STAMP(5);
+}
+
+}  // namespace nfp

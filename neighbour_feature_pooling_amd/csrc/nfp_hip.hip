@@ -17,6 +17,7 @@
 #include <cstdlib>
 
 #include "nfp_fast.h"
+#include "nfp_band.h"
 #include "nfp_gather.h"
 #include "nfp_mfma.h"
 #include "nfp_generic.h"
@@ -43,7 +44,7 @@ void publish_variant() {
 // Test / A-B switches, read from the environment ONCE when the library is loaded (and again only when a test
 // calls nfp_reload_env): the launch path itself never calls getenv.
 struct Switches {
-  std::atomic<int> fwd_scalar{0}, bwd_atomic{0}, bwd_bands{0}, force_generic{0}, mfma{1};
+  std::atomic<int> fwd_scalar{0}, bwd_atomic{0}, bwd_bands{0}, force_generic{0}, mfma{1}, fwd_band{1};
 };
 Switches g_sw;
 #ifndef NFP_MFMA_DEFAULT
@@ -58,6 +59,7 @@ void read_env() {
   g_sw.bwd_atomic = flag("NFP_BWD_ATOMIC", 0);
   g_sw.force_generic = flag("NFP_FORCE_GENERIC", 0);
   g_sw.mfma = flag("NFP_MFMA", NFP_MFMA_DEFAULT);
+  g_sw.fwd_band = flag("NFP_FWD_BAND", 1);
   const char* e = getenv("NFP_BWD_BANDS");
   g_sw.bwd_bands = e ? atoi(e) : 0;
 }
@@ -542,6 +544,43 @@ int launch_fwd_fast_t(KP g, const void* x, void* out, float* saved, hipStream_t 
                 nfpm);
 }
 
+// Row-banded forward (nfp_band.h): needs the descriptor's workspace tables.
+#ifndef NFP_BAND_WGS
+#define NFP_BAND_WGS 256
+#endif
+template <int R, int M, bool BF, bool NHWC>
+int launch_fwd_band_t(KP g, const void* x, void* out, float* saved, hipStream_t st) {
+  constexpr int NF = Win<R>::NF;
+  int nb = std::min(g.H, (NFP_BAND_WGS + g.B - 1) / g.B);   // bands per image so that >= NFP_BAND_WGS workgroups exist
+  const int rb = (g.H + nb - 1) / nb;
+  nb = (g.H + rb - 1) / rb;
+  const int psm = std::min(g.P, (rb + g.R) * g.W);          // most pixels a band stages
+  const int gmin = std::max(1, std::min(kBandT / psm, g.C / 4));
+  const int nqb = (psm + 3) / 4 + 1, ppb = psm + 3 + 8;     // blocks / slots per slab row, alignment slack included
+  int ncq = (NFP_FWD_SLAB_KB * 1024) / (ppb * 16);
+  ncq = std::min(ncq, NHWC ? kBandRN * gmin : (kBandRB * kBandT) / nqb);
+  if (ncq < 1) return kNotApplicable;
+  const int total = g.C / 4, nch = (total + ncq - 1) / ncq;
+  g.Cc = 4 * ((total + nch - 1) / nch);
+  const size_t slab = (size_t)(g.Cc / 4) * ppb * 16;
+  const size_t red = (size_t)(kBandT + psm) * (NF + 1) * 4;
+  const size_t lds = std::max(slab, red);
+  if (lds > (size_t)kLdsMax) return kNotApplicable;
+  snprintf(g_variant, sizeof(g_variant), "fwd_band<R%d,%s,%s,%s>x%d", R, M == NFP_COSINE ? "cos" : "l2", BF ? "bf16" : "f32",
+           NHWC ? "nhwc" : "nchw", nb);
+  return launch("fwd_band", fwd_band<R, M, BF, NHWC>, dim3(g.B, nb), dim3(kBandT), lds, st, g, x, out, saved, g.ws, rb);
+}
+
+template <int R, int M>
+int launch_fwd_band(const KP& g, const void* x, void* out, float* saved, hipStream_t st) {
+  if (g.ws == nullptr || g_sw.fwd_band.load(std::memory_order_relaxed) == 0) return kNotApplicable;
+  const bool bf = g.dtype == NFP_BF16, nhwc = !g.contig;
+  if (bf) return nhwc ? launch_fwd_band_t<R, M, true, true>(g, x, out, saved, st)
+                      : launch_fwd_band_t<R, M, true, false>(g, x, out, saved, st);
+  return nhwc ? launch_fwd_band_t<R, M, false, true>(g, x, out, saved, st)
+              : launch_fwd_band_t<R, M, false, false>(g, x, out, saved, st);
+}
+
 template <int R, int M>
 int launch_fwd_fast(const KP& g, const void* x, void* out, float* saved, hipStream_t st) {
   const bool bf = g.dtype == NFP_BF16, nhwc = !g.contig;
@@ -726,6 +765,13 @@ int forward_impl(const nfp_desc* d, const void* x, void* out, float* saved, void
     else
       rc = g.R == 1 ? launch_fwd_gram<1, NFP_NORM>(g, x, out, saved, st)
                     : launch_fwd_gram<2, NFP_NORM>(g, x, out, saved, st);
+    if (rc != kNotApplicable) return rc;
+    if (g.measure == NFP_COSINE)
+      rc = g.R == 1 ? launch_fwd_band<1, NFP_COSINE>(g, x, out, saved, st)
+                    : launch_fwd_band<2, NFP_COSINE>(g, x, out, saved, st);
+    else
+      rc = g.R == 1 ? launch_fwd_band<1, NFP_NORM>(g, x, out, saved, st)
+                    : launch_fwd_band<2, NFP_NORM>(g, x, out, saved, st);
     if (rc != kNotApplicable) return rc;
     if (g.measure == NFP_COSINE)
       rc = g.R == 1 ? launch_fwd_fast<1, NFP_COSINE>(g, x, out, saved, st)

@@ -16,7 +16,8 @@
 //   tq    [P*K2]     u16   pixel t under slot j of r, 0xFFFF outside the image
 //   mask  [P][2]     u32   bit n set: tap n of pixel p reads zero padding / reads p itself (reflect on tiny maps)
 //   ft    [N*P]      u32   forward: output (n, p) = q | pix << 9 | fi << 18 | kind << 22 — neighbour pixel q, the
-//                          half-stencil entry Tt[fi][pix] holding its pair sum, kind 0 pair / 1 self / 2 zero pad
+//                          half-stencil entry Tt[fi][pix] holding its pair sum (pix = the pair's forward end, p
+//                          itself for the other kinds), kind 0 pair / 1 self / 2 zero pad
 //   boff  [P][BR]    i16   backward: LDS float4-slot offset of window slot j from the pixel's own slot (0 outside)
 //   foff  [P][FR]    i16   forward: the same for the NF forward directions
 #pragma once
@@ -184,8 +185,8 @@ __global__ void __launch_bounds__(256) fill_workspace(const KP g, unsigned char*
     const bool fwd = dy > 0 || (dy == 0 && dx > 0);
     const bool pair = q >= 0 && q != p;
     const int fi = pair ? (fwd ? fidx<R>(dy, dx) : fidx<R>(-dy, -dx)) : 0;
-    const int pix = fwd ? p : qc;
     const int kind = q < 0 ? 2 : (q == p ? 1 : 0);
+    const int pix = kind == 0 ? (fwd ? p : qc) : p;  // the pixel whose band writes the output: the pair's forward end
     ft[i] = (uint32_t)qc | ((uint32_t)pix << 9) | ((uint32_t)fi << 18) | ((uint32_t)kind << 22);
   }
 }

@@ -111,8 +111,8 @@ def test_plan_is_reentrant_and_last_variant_is_stable(lib):
     publishes nothing) or be torn."""
     import threading
     before = lib.nfp_last_variant()
-    want = {"a": (_desc((64, 512, 7, 7)), b"fwd_fast<R1,cos,f32,nchw>"),
-            "b": (_desc((4, 192, 14, 14), R=2, pad=2, measure="norm"), b"fwd_fast<R2,l2,f32,nchw>")}
+    want = {"a": (_desc((64, 512, 7, 7)), b"fwd_band<R1,cos,f32,nchw>"),
+            "b": (_desc((4, 192, 14, 14), R=2, pad=2, measure="norm"), b"fwd_band<R2,l2,f32,nchw>")}
     want["b"][0].diff_weights = 1
     errors, stop = [], threading.Event()
 
@@ -157,12 +157,12 @@ def test_env_switches_take_effect_only_through_reload(lib, monkeypatch):
     d = _desc((64, 512, 7, 7))
     buf = ctypes.create_string_buffer(1024)
     monkeypatch.setenv("NFP_FORCE_GENERIC", "1")
-    assert lib.nfp_plan(ctypes.byref(d), 0, buf, len(buf)) == 0 and buf.value.startswith(b"fwd_fast")
+    assert lib.nfp_plan(ctypes.byref(d), 0, buf, len(buf)) == 0 and buf.value.startswith(b"fwd_band")
     lib.nfp_reload_env()
     assert lib.nfp_plan(ctypes.byref(d), 0, buf, len(buf)) == 0 and buf.value.startswith(b"fwd_pairs")
     monkeypatch.delenv("NFP_FORCE_GENERIC")
     lib.nfp_reload_env()
-    assert lib.nfp_plan(ctypes.byref(d), 0, buf, len(buf)) == 0 and buf.value.startswith(b"fwd_fast")
+    assert lib.nfp_plan(ctypes.byref(d), 0, buf, len(buf)) == 0 and buf.value.startswith(b"fwd_band")
 
 
 def test_workspace_bytes(lib):

@@ -49,17 +49,18 @@ def launches(text):
 def test_plan_does_not_launch_or_disturb_last_variant(lib):
     before, n0 = lib.nfp_last_variant(), lib.nfp_launch_count()
     rc, text = plan(lib, desc((64, 512, 7, 7)), False)
-    assert rc == 0 and text.startswith("fwd_fast<R1,cos,f32,nchw> | fwd_fast grid=(64,1,1)")
+    assert rc == 0 and text.startswith("fwd_band<R1,cos,f32,nchw>x4 | fwd_band grid=(64,4,1)")
     assert lib.nfp_launch_count() == n0 and lib.nfp_last_variant() == before
 
 
 @pytest.mark.parametrize("d_kw,fwd,bwd", [
-    (dict(shape=(64, 512, 7, 7)), "fwd_fast<R1,cos,f32,nchw>", "bwd_fast<R1,cos,f32,nchw>"),           # headline
+    (dict(shape=(64, 512, 7, 7)), "fwd_band<R1,cos,f32,nchw>x4", "bwd_fast<R1,cos,f32,nchw>"),         # headline: 4 row bands
+    (dict(shape=(256, 512, 7, 7)), "fwd_band<R1,cos,f32,nchw>x1", "bwd_fast<R1,cos,f32,nchw>"),        # config 4: whole images
     (dict(shape=(256, 192, 14, 14), R=2, measure="norm", dtype=_abi.BF16), "fwd_gram<R2,l2,bf16,nchw>",
      "bwd_fast<R2,l2,bf16,nchw,mfma>"),                                                                 # config 5
-    (dict(shape=(256, 200, 14, 14), R=2, measure="norm", dtype=_abi.BF16), "fwd_fast<R2,l2,bf16,nchw>",
+    (dict(shape=(256, 200, 14, 14), R=2, measure="norm", dtype=_abi.BF16), "fwd_band<R2,l2,bf16,nchw>x1",
      "bwd_fast<R2,l2,bf16,nchw>"),                                                                      # C % 16 != 0
-    (dict(shape=(8, 512, 7, 7), channels_last=True), "fwd_fast<R1,cos,f32,nhwc>", "bwd_fast<R1,cos,f32,nhwc>"),
+    (dict(shape=(8, 512, 7, 7), channels_last=True), "fwd_band<R1,cos,f32,nhwc>x7", "bwd_fast<R1,cos,f32,nhwc>"),
     (dict(shape=(256, 192, 14, 14), R=2, measure="norm", dtype=_abi.BF16, channels_last=True),
      "fwd_gram<R2,l2,bf16,nhwc>", "bwd_fast<R2,l2,bf16,nhwc,mfma>"),                                    # ViT tokens: matrix cores
     (dict(shape=(256, 512, 7, 7), dtype=_abi.BF16), "fwd_gram<R1,cos,bf16,nchw>", "bwd_fast<R1,cos,bf16,nchw>"),   # odd rows, no channel split
@@ -120,4 +121,4 @@ def test_every_accepted_descriptor_launches_within_device_limits(lib):
                 assert lds <= LDS_MAX and 1 <= block <= 1024, text
                 assert all(v >= 1 for v in grid) and grid[1] <= 65535 and grid[2] <= 65535, text
     assert accepted > 2000
-    assert {"fwd_fast", "fwd_gram", "bwd_fast", "fwd_pairs", "bwd_gather", "bwd_gather_banded"} <= seen, seen
+    assert {"fwd_band", "fwd_gram", "bwd_fast", "fwd_pairs", "bwd_gather", "bwd_gather_banded"} <= seen, seen
