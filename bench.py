@@ -3,20 +3,27 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
 
-A step = one NFPPooling forward + one backward (given grad_out) over one batch of
-synthetic feature maps already resident in HBM, through the product path (nn.Module ->
-autograd -> C ABI -> HIP kernels).  Workload at every N: BASELINE.json configs[1],
-NFP(cosine, k=3) on [B=64, C=512, 7x7] fp32 per GPU (weak scaling: every rank owns its
-own batch; the path has no exchange step, so there is no collective in the timed region
-beyond the bracketing barriers).  Prints ONE JSON line on rank 0.
+A step = one NFPPooling forward + one backward (given grad_out) over one batch of synthetic feature maps
+already resident in HBM, through the product path (nn.Module -> autograd -> C ABI -> HIP kernels).
+Workload at every N: BASELINE.json configs[1], NFP(cosine, k=3) on [B=64, C=512, 7x7] fp32 per GPU (weak
+scaling: every rank owns its own batch; the path has no exchange step, so there is no collective in the
+timed region beyond the bracketing barriers).  Prints ONE JSON line on rank 0.
 
-The K timed steps are captured once into a HIP graph and replayed (`--launch eager`
-times plain launches instead): at this size a step is ~10 us of GPU work, far below the
-host cost of two Python->ctypes->hipLaunch round trips.
+Two legs:
+  * `value` / `ms_per_step` / `roofline`: the ROTATING leg — step i works on buffer set i mod S, S sets of
+    (x, grad_out) holding more than 256 MiB of x alone, so that no step finds its input in the 256 MiB
+    Infinity Cache: x, grad_out and grad_x are HBM traffic (within a step the backward re-reads the x its
+    forward read microseconds before).  This is the figure the HBM roofline fraction is quoted on.
+  * `cache_resident`: the same K steps on ONE buffer set (6.4 MB of x: served by L2 / Infinity Cache after the
+    first step) — what a training step sees when the backbone has just written the feature map.
+The K timed steps are captured once into a HIP graph and replayed (`--launch eager` times plain launches
+instead): a step is ~11 us of GPU work, far below the host cost of two Python->ctypes->hipLaunch round trips.
 """
 import argparse
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -26,9 +33,10 @@ sys.path.insert(0, ROOT)
 import torch
 
 HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md); 6290 GB/s is the measured-achievable copy rate
+INFINITY_CACHE_BYTES = 256 << 20
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -40,9 +48,14 @@ def parse():
     ap.add_argument("--radius", type=int, default=1)
     ap.add_argument("--measure", default="cosine")
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32")
+    ap.add_argument("--layout", choices=["nchw", "nhwc"], default="nchw")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
-    return ap.parse_args()
+    ap.add_argument("--no-extras", action="store_true", help="skip the cache-resident, ReLU-input, saturating-batch and "
+                    "live-traffic legs: every NFP launch of the process then belongs to the rotating leg, so a rocprofv3 "
+                    "--kernel-trace --stats summary of the run averages exactly the launches `roofline` is quoted on")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)  # run under rocprofv3 --pmc by bench.py itself
+    return ap.parse_args(argv)
 
 
 def algorithmic_bytes(B, C, HW, N, e):
@@ -51,25 +64,30 @@ def algorithmic_bytes(B, C, HW, N, e):
     return px * (C * e + N * e), px * (2 * C * e + N * e)
 
 
-def time_kernel_graph(fn, reps, stream):
-    """Average duration of `fn`'s kernel: `reps` back-to-back launches captured in one HIP
-    graph, bracketed by events on the launch stream."""
+def time_graph(fns, stream, repeats=5):
+    """Average duration (us) of one call: the calls `fns` (a list, run in order) are captured into one HIP graph
+    and replayed, bracketed by events on the launch stream; median of `repeats` replays."""
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g, stream=stream):
-        for _ in range(reps):
-            fn()
+        keep = [fn() for fn in fns]   # (results stay alive inside the graph's pool: distinct output buffers)
+    del keep
     g.replay()
     torch.cuda.synchronize()
-    best = []
-    for _ in range(5):
+    ts = []
+    for _ in range(repeats):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         g.replay()
         e1.record()
         e1.synchronize()
-        best.append(e0.elapsed_time(e1) * 1e3 / reps)  # us
-    best.sort()
-    return best[len(best) // 2]
+        ts.append(e0.elapsed_time(e1) * 1e3 / len(fns))
+    ts.sort()
+    return ts[len(ts) // 2]
+
+
+def time_kernel_graph(fn, reps, stream):
+    """One callable repeated `reps` times (scripts/ab_flags.py and friends use this form)."""
+    return time_graph([fn] * reps, stream)
 
 
 def usable_cpus():
@@ -84,16 +102,20 @@ def usable_cpus():
     return n
 
 
+def module_ctor(args):
+    ctor = dict(R=args.radius, measure=args.measure, padding=args.radius)
+    if args.measure == "norm":
+        ctor["p"] = 2
+    return ctor
+
+
 def cpu_baseline(args, budget_s):
     """The reference's CPU op sequence (oracle/unfold_torch.py) on this box's host cores,
     same [B,C,H,W] workload, bounded to ~budget_s seconds.  The thread count is the fastest of a
     few candidates (torch's default of one thread per logical CPU oversubscribes a shared box)."""
     from oracle.unfold_torch import UnfoldNFP
     B, C, S = args.batch, args.channels, args.size
-    ctor = dict(R=args.radius, measure=args.measure, padding=args.radius)
-    if args.measure == "norm":
-        ctor["p"] = 2
-    m = UnfoldNFP(C, **ctor)
+    m = UnfoldNFP(C, **module_ctor(args))
     x = torch.randn(B, C, S, S, requires_grad=True)
     go = torch.randn(B, m.N, S, S)
 
@@ -136,10 +158,7 @@ def unfold_on_gpu(args, dev, steps=50):
     is timed: K steps in one HIP graph, and eager."""
     from oracle.unfold_torch import UnfoldNFP
     B, C, S = args.batch, args.channels, args.size
-    ctor = dict(R=args.radius, measure=args.measure, padding=args.radius)
-    if args.measure == "norm":
-        ctor["p"] = 2
-    m = UnfoldNFP(C, **ctor)
+    m = UnfoldNFP(C, **module_ctor(args))
     dtype = torch.float32 if args.dtype == "f32" else torch.bfloat16
     m.w_comp, m.w_centre = m.w_comp.to(dev, dtype), m.w_centre.to(dev, dtype)
     x = torch.randn(B, C, S, S, device=dev, dtype=dtype, requires_grad=True)
@@ -185,27 +204,184 @@ def workload_key(args):
     return f"{args.batch}x{args.channels}x{args.size}x{args.size} k{2 * args.radius + 1} {args.measure} {args.dtype}"
 
 
-def pmc_traffic(kernel_prefix, args):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes
-    (profiles/traffic_latest.json, written by scripts/gpu_traffic.sh: FETCH_SIZE and WRITE_SIZE in
-    separate rocprofv3 --pmc runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for
-    16-byte-per-lane streaming reads on gfx950).  None when no profile of THIS workload is committed."""
-    path = os.path.join(ROOT, "profiles", "traffic_latest.json")
+def source_hash():
+    """Hash of the kernel sources: a committed traffic profile is only reported for the code it was measured on
+    (the GPU box has no .git, so the commit id is not available there)."""
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "neighbour_feature_pooling_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        h.update(f.encode())
+        h.update(open(os.path.join(csrc, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def committed_traffic(kernel, args):
+    """HBM bytes per launch of `kernel` from profiles/traffic_latest.json (scripts/gpu_traffic.sh) — only when that
+    file was measured on THESE kernel sources and this workload; otherwise None."""
     try:
-        rec = json.load(open(path))
+        rec = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))
     except (OSError, ValueError):
         return None
-    kernels = rec.get("workloads", {}).get(workload_key(args))
-    if kernels is None and workload_key(args) == "64x512x7x7 k3 cosine f32":
-        kernels = rec.get("kernels", {})   # first-generation file: headline workload only
-    for k, v in (kernels or {}).items():
-        if k.startswith(kernel_prefix):
+    if rec.get("source_hash") != source_hash():
+        return None
+    for k, v in (rec.get("workloads", {}).get(workload_key(args)) or {}).items():
+        if k.startswith(kernel):
             return v.get("hbm_bytes_per_launch")
     return None
 
 
+def live_traffic(kernel, argv):
+    """FETCH_SIZE and WRITE_SIZE of `kernel` measured NOW: this script re-runs itself (--pmc-child: a short rotating
+    loop, nothing else) under `rocprofv3 --pmc`, one counter per pass as MI355X_MICROARCH.md prescribes (TCC has 4
+    slots; FETCH_SIZE takes 3, WRITE_SIZE 2), kernel-trace only.  hbm bytes per launch = (2*FETCH_SIZE +
+    WRITE_SIZE) KiB: on gfx950 FETCH_SIZE counts the 128-byte requests of 16-byte-per-lane streaming reads at 64 bytes.
+    Returns (bytes, detail) or (None, reason)."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    rocprof = shutil.which("rocprofv3")
+    if rocprof is None:
+        return None, "rocprofv3 not on PATH"
+    vals = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="nfp_pmc_", dir="/tmp")
+        cmd = [rocprof, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "pmc", "--",
+               sys.executable, os.path.abspath(__file__), "--pmc-child"] + argv
+        try:
+            env = dict(os.environ, TMPDIR="/tmp")
+            subprocess.run(cmd, cwd="/tmp", env=env, timeout=150, check=True, stdout=subprocess.DEVNULL,
+                           stderr=subprocess.DEVNULL)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            per = [float(r["Counter_Value"]) for r in csv.DictReader(open(files[0]))
+                   if r["Counter_Name"] == counter and ("nfp::" + kernel) in r["Kernel_Name"]]
+            if not per:
+                return None, f"no {kernel} dispatch in the {counter} pass"
+            vals[counter] = sum(per) / len(per)
+        except Exception as exc:   # profiler missing / refused / timed out: the committed profile or null
+            return None, f"{counter} pass failed: {type(exc).__name__}"
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    b = int((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024)
+    return b, {"FETCH_SIZE_KB": round(vals["FETCH_SIZE"], 1), "WRITE_SIZE_KB": round(vals["WRITE_SIZE"], 1),
+               "read_bytes": int(2 * vals["FETCH_SIZE"] * 1024), "write_bytes": int(vals["WRITE_SIZE"] * 1024)}
+
+
+class KernelTimer:
+    """Per-kernel durations the way a profiler's kernel trace measures them: libnfp_hip.so brackets a launch with two
+    HIP events recorded at the kernel's own start and end (include/nfp.h: nfp_time_next_launch)."""
+
+    def __init__(self, L):
+        import ctypes
+        self.ct, self.L = ctypes, L
+        self.hip = ctypes.CDLL("libamdhip64.so")
+        self.hip.hipEventElapsedTime.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.c_void_p, ctypes.c_void_p]
+
+    def _event(self):
+        ev = self.ct.c_void_p()
+        assert self.hip.hipEventCreate(self.ct.byref(ev)) == 0
+        return ev
+
+    def measure(self, launches):
+        """launches: callables that each enqueue exactly ONE nfp kernel first.  Returns their durations in us."""
+        pairs = []
+        for fn in launches:
+            e0, e1 = self._event(), self._event()
+            self.L.nfp_time_next_launch(e0, e1)
+            fn()
+            pairs.append((e0, e1))
+        torch.cuda.synchronize()
+        out = []
+        for e0, e1 in pairs:
+            ms = self.ct.c_float()
+            assert self.hip.hipEventElapsedTime(self.ct.byref(ms), e0, e1) == 0
+            out.append(ms.value * 1e3)
+            self.hip.hipEventDestroy(e0)
+            self.hip.hipEventDestroy(e1)
+        return out
+
+
+def median(v):
+    v = sorted(v)
+    return v[len(v) // 2]
+
+
+class Workload:
+    """S rotating sets of (x, grad_out) for one module; `step(i)` = product forward + backward on set i mod S."""
+
+    def __init__(self, args, dev, rank, batch=None, sets=None, relu=False):
+        from neighbour_feature_pooling_amd import NFPPooling
+        self.B = batch or args.batch
+        C, S_, R = args.channels, args.size, args.radius
+        self.dtype = torch.float32 if args.dtype == "f32" else torch.bfloat16
+        self.m = NFPPooling(C, **module_ctor(args))
+        self.N = self.m.out_channels
+        e = 4 if args.dtype == "f32" else 2
+        x_bytes = self.B * C * S_ * S_ * e
+        self.sets = sets if sets is not None else INFINITY_CACHE_BYTES // x_bytes + 2   # x alone exceeds the cache
+        gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+        self.x, self.go = [], []
+        for _ in range(self.sets):
+            x = torch.randn(self.B, C, S_, S_, device=dev, generator=gen)
+            if relu:
+                x = x.relu()
+            x = x.to(self.dtype)
+            if args.layout == "nhwc":
+                x = x.contiguous(memory_format=torch.channels_last)
+            self.x.append(x.requires_grad_(True))
+            self.go.append(torch.randn(self.B, self.N, S_, S_, device=dev, generator=gen).to(self.dtype))
+        self.fb, self.bb = algorithmic_bytes(self.B, C, S_ * S_, self.N, e)
+
+    def step(self, i=0):
+        k = i % self.sets
+        out = self.m(self.x[k])
+        (gx,) = torch.autograd.grad(out, self.x[k], self.go[k])
+        return out, gx
+
+    def kernel_events(self, timer, stream, rounds=2):
+        """(forward us, backward us): each kernel of `rounds` passes over the sets (eager steps, forward then
+        backward of the same set, as the timed region orders them) bracketed by its own pair of events; means."""
+        tf, tb = [], []
+        with torch.cuda.stream(stream):
+            for i in range(rounds * self.sets):
+                k = i % self.sets
+                out = []
+                tf += timer.measure([lambda: out.append(self.m(self.x[k]))])
+                tb += timer.measure([lambda: torch.autograd.grad(out[0], self.x[k], self.go[k])])
+        return sum(tf) / len(tf), sum(tb) / len(tb), median(tf), median(tb)
+
+    def kernel_times(self, stream, reps=None, isolated_backward=False):
+        """(forward us, backward us) per launch over the sets, HIP events around captured graphs on the launch
+        stream.  The backward is timed IN the step sequence — a graph of `reps` steps minus a graph of the same
+        `reps` forwards — i.e. as the timed region runs it: grad_out / out / grad_x are HBM traffic, x was read by
+        the step's forward a few microseconds earlier.  isolated_backward=True times backward launches alone
+        instead (x from HBM too when the sets rotate)."""
+        reps = reps or max(self.sets, 40)
+        with torch.cuda.stream(stream):
+            tf = time_graph([(lambda k=i % self.sets: self.m(self.x[k])) for i in range(reps)], stream)
+            if isolated_backward:
+                outs = [self.m(self.x[k]) for k in range(self.sets)]
+                tb = time_graph([(lambda k=i % self.sets: torch.autograd.grad(outs[k], self.x[k], self.go[k], retain_graph=True))
+                                 for i in range(reps)], stream)
+            else:
+                tb = time_graph([(lambda k=i: self.step(k)) for i in range(reps)], stream) - tf
+        return tf, tb
+
+
+def pmc_child(args):
+    """What rocprofv3 --pmc profiles: 24 rotating steps of the default workload, nothing else."""
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    w = Workload(args, dev, 0)
+    for i in range(24):
+        w.step(i)
+    torch.cuda.synchronize()
+
+
 def main():
     args = parse()
+    if args.pmc_child:
+        return pmc_child(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -224,108 +400,146 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
-    from neighbour_feature_pooling_amd import NFPPooling, _abi
+    from neighbour_feature_pooling_amd import _abi
     L = _abi.load()
     B, C, S, R = args.batch, args.channels, args.size, args.radius
-    dtype = torch.float32 if args.dtype == "f32" else torch.bfloat16
-    ctor = dict(R=R, measure=args.measure, padding=R)
-    if args.measure == "norm":
-        ctor["p"] = 2
-    m = NFPPooling(C, **ctor)
-    N = m.out_channels
-    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
-    x = torch.randn(B, C, S, S, device=dev, generator=gen).to(dtype).requires_grad_(True)
-    go = torch.randn(B, N, S, S, device=dev, generator=gen).to(dtype)
-
-    def step():
-        out = m(x)
-        (gx,) = torch.autograd.grad(out, x, go)
-        return out, gx
+    rot = Workload(args, dev, rank)               # the timed leg: rotating sets, every byte from HBM
+    hot = Workload(args, dev, rank, sets=1)       # one resident set
 
     def barrier():
         if dist is not None:
             dist.barrier()
 
     stream = torch.cuda.Stream(device=dev)
-    with torch.cuda.stream(stream):
-        for _ in range(args.warmup):
-            step()
-    torch.cuda.synchronize()
-    n_before = L.nfp_launch_count()
 
-    if args.launch == "graph":
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, stream=stream):
-            for _ in range(args.steps):
-                step()
-        torch.cuda.synchronize()
-        graph.replay()  # untimed: first replay uploads the graph
-        torch.cuda.synchronize()
-        barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        graph.replay()
-        torch.cuda.synchronize()
-        barrier()
-        t1 = time.perf_counter()
-    else:
-        barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
+    def timed(w):
+        """K steps of workload `w` on `stream`: (elapsed seconds, launches counted by the library)."""
         with torch.cuda.stream(stream):
-            for _ in range(args.steps):
-                step()
+            for i in range(args.warmup):
+                w.step(i)
         torch.cuda.synchronize()
-        barrier()
-        t1 = time.perf_counter()
-    assert L.nfp_launch_count() >= n_before + 2 * args.steps, "HIP kernels did not run"
-    fwd_variant = bwd_variant = ""
-    with torch.cuda.stream(stream):
-        out = m(x)
-        fwd_variant = L.nfp_last_variant().decode()
-        torch.autograd.grad(out, x, go)
-        bwd_variant = L.nfp_last_variant().decode()
+        n0 = L.nfp_launch_count()
+        if args.launch == "graph":
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=stream):
+                keep = [w.step(i) for i in range(args.steps)]
+            del keep
+            n_graph = L.nfp_launch_count() - n0
+            torch.cuda.synchronize()
+            graph.replay()  # untimed: first replay uploads the graph
+            torch.cuda.synchronize()
+            barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            graph.replay()
+            torch.cuda.synchronize()
+            barrier()
+            t1 = time.perf_counter()
+            del graph
+        else:
+            barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            with torch.cuda.stream(stream):
+                for i in range(args.steps):
+                    w.step(i)
+            torch.cuda.synchronize()
+            barrier()
+            t1 = time.perf_counter()
+            n_graph = L.nfp_launch_count() - n0
+        assert n_graph >= 2 * args.steps, "HIP kernels did not run"
+        return t1 - t0
 
     from neighbour_feature_pooling_amd.parallel import max_over_ranks
-    elapsed = max_over_ranks(t1 - t0, device=dev if backend == "nccl" else "cpu")
+    red_dev = dev if backend == "nccl" else "cpu"
+    elapsed = max_over_ranks(timed(rot), device=red_dev)
+    extras = world == 1 and not args.no_extras
+    elapsed_hot = timed(hot) if extras else None
+    with torch.cuda.stream(stream):
+        out = hot.m(hot.x[0])
+        fwd_variant = L.nfp_last_variant().decode()
+        torch.autograd.grad(out, hot.x[0], hot.go[0])
+        torch.cuda.synchronize()
+        bwd_variant = L.nfp_last_variant().decode()
     px_per_step = B * S * S
     value = world * px_per_step * args.steps / elapsed / 1e6
 
     res = None
     if rank == 0:
-        # per-kernel timing on the launch stream (HIP events around graph-replayed back-to-back launches)
-        e = 4 if args.dtype == "f32" else 2
-        fb, bb = algorithmic_bytes(B, C, S * S, N, e)
-        with torch.cuda.stream(stream):
-            out = m(x)
-            xd = x.detach()
-            with torch.no_grad():
-                t_fwd = time_kernel_graph(lambda: m(xd), 50, stream)
-            t_fwd_saving = time_kernel_graph(lambda: m(x), 50, stream)
-            t_bwd = time_kernel_graph(lambda: torch.autograd.grad(out, x, go, retain_graph=True), 50, stream)
-        dom_bytes, dom_t, dom = (bb, t_bwd, "backward") if t_bwd >= t_fwd_saving else (fb, t_fwd_saving, "forward")
+        timer = KernelTimer(L)
+        tf, tb, tf_med, tb_med = rot.kernel_events(timer, stream)   # per-kernel HIP events on the launch stream
+        tf_graph, tb_graph = rot.kernel_times(stream)               # and: graph-replayed launches / count (gaps included)
+        dom_bytes, dom_t, dom, dom_variant = ((rot.bb, tb, "backward", bwd_variant) if tb >= tf else
+                                              (rot.fb, tf, "forward", fwd_variant))
         achieved = dom_bytes / (dom_t * 1e-6) / 1e9
+        dom_kernel = dom_variant.split("<")[0].split("+")[0]
+        traffic, traffic_src = None, None
+        if extras:
+            traffic, traffic_src = live_traffic(dom_kernel, [a for a in sys.argv[1:] if a not in ("--no-cpu-baseline",)])
+        if traffic is None:
+            why = traffic_src
+            traffic = committed_traffic(dom_kernel, args)
+            traffic_src = ("profiles/traffic_latest.json (same kernel sources)" if traffic is not None
+                           else f"none ({why or 'no live pass'}; no committed profile of these sources)")
+        e = 4 if args.dtype == "f32" else 2
         res = {
-            "metric": "NFP fwd+bwd Mpixels/s @ [B64,C512,7\u00d77,k3]; 1/2/4/8 GPU + %HBM roofline",
+            "metric": "NFP fwd+bwd Mpixels/s @ [B64,C512,7×7,k3]; 1/2/4/8 GPU + %HBM roofline",
             "value": round(value, 3), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 6),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
             "data": "synthetic",
             "config": {"workload": f"NFP({args.measure},k={2 * R + 1},reflect pad {R}) fwd+bwd on "
-                                   f"[{B},{C},{S},{S}] {args.dtype} NCHW per GPU (BASELINE.json configs[1])",
+                                   f"[{B},{C},{S},{S}] {args.dtype} {args.layout.upper()} per GPU (BASELINE.json configs[1])",
                        "batch_per_gpu": B, "global_batch": B * world, "launch": args.launch,
+                       "buffers": f"rotating: {rot.sets} sets of (x, grad_out), {rot.sets * rot.B * C * S * S * e >> 20} MiB of x "
+                                  f"per GPU (> 256 MiB Infinity Cache): every step reads its input from HBM",
                        "parallelism": f"batch-sharded replicas x{world}, no data-path collective"},
-            "roofline": {"bound": "hbm", "kernel": f"{dom}:{bwd_variant if dom == 'backward' else fwd_variant}",
+            "roofline": {"bound": "hbm", "leg": "rotating buffers, kernel timed inside the step sequence (grad_out, out and "
+                                                  "grad_x are HBM traffic; the backward re-reads the x its forward read "
+                                                  "microseconds earlier)",
+                         "kernel": f"{dom}:{dom_variant}",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": pmc_traffic((bwd_variant if dom == "backward" else fwd_variant)
-                                                .split("<")[0].split("+")[0], args),
+                         "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_us": round(dom_t, 3)},
-            "kernels": {"forward_us": round(t_fwd_saving, 3), "forward_nograd_us": round(t_fwd, 3),
-                        "backward_us": round(t_bwd, 3), "forward_variant": fwd_variant,
-                        "backward_variant": bwd_variant, "fwd_bytes": fb, "bwd_bytes": bb,
-                        "fwd_GBs": round(fb / t_fwd_saving / 1e3, 1), "bwd_GBs": round(bb / t_bwd / 1e3, 1)},
+            "kernels": {"how": "forward_us / backward_us: mean over 2 passes of the rotating sets of each launch's own HIP "
+                               "event pair (hipExtLaunchKernel: kernel start to kernel end, what rocprofv3's kernel "
+                               "trace reports); *_graph_us: K graph-replayed launches / K, inter-kernel gaps included",
+                        "forward_us": round(tf, 3), "backward_us": round(tb, 3),
+                        "forward_median_us": round(tf_med, 3), "backward_median_us": round(tb_med, 3),
+                        "forward_graph_us": round(tf_graph, 3), "backward_graph_us": round(tb_graph, 3),
+                        "forward_variant": fwd_variant, "backward_variant": bwd_variant,
+                        "fwd_bytes": rot.fb, "bwd_bytes": rot.bb,
+                        "fwd_GBs": round(rot.fb / tf / 1e3, 1), "bwd_GBs": round(rot.bb / tb / 1e3, 1)},
         }
+        if extras:
+            tf_hot, tb_hot, _, _ = hot.kernel_events(timer, stream, rounds=50)
+            res["cache_resident"] = {"what": "the same K steps on ONE buffer set (inputs served by L2 / Infinity Cache)",
+                                     "value": round(px_per_step * args.steps / elapsed_hot / 1e6, 3),
+                                     "ms_per_step": round(elapsed_hot / args.steps * 1e3, 6),
+                                     "forward_us": round(tf_hot, 3), "backward_us": round(tb_hot, 3),
+                                     "fwd_GBs": round(rot.fb / tf_hot / 1e3, 1), "bwd_GBs": round(rot.bb / tb_hot / 1e3, 1)}
+            rl = Workload(args, dev, rank, relu=True)                       # what a ResNet trunk emits: x >= 0, ~50 % zeros
+            rf, rbk, _, _ = rl.kernel_events(timer, stream)
+            res["relu_input"] = {"what": "the same workload with x = relu(randn): non-negative, about half zeros",
+                                 "forward_us": round(rf, 3), "backward_us": round(rbk, 3),
+                                 "value": round(px_per_step / (rf + rbk), 3), "unit": "Mpixels/s (kernel time)"}
+            del rl
+            big = Workload(args, dev, rank, batch=4096, sets=2)            # 0.8 GB of x per set: far beyond every cache
+            bf_, bb_, _, _ = big.kernel_events(timer, stream, rounds=3)
+            with torch.cuda.stream(stream):
+                o = big.m(big.x[0])
+                bfv = L.nfp_last_variant().decode()
+                torch.autograd.grad(o, big.x[0], big.go[0])
+                torch.cuda.synchronize()
+                bbv = L.nfp_last_variant().decode()
+            res["saturating_batch"] = {"batch": 4096, "forward_us": round(bf_, 2), "backward_us": round(bb_, 2),
+                                       "forward_variant": bfv, "backward_variant": bbv,
+                                       "fwd_GBs": round(big.fb / bf_ / 1e3, 1), "bwd_GBs": round(big.bb / bb_ / 1e3, 1),
+                                       "fwd_frac_of_peak": round(big.fb / bf_ / 1e3 / HBM_PEAK_GBS, 4),
+                                       "bwd_frac_of_peak": round(big.bb / bb_ / 1e3 / HBM_PEAK_GBS, 4),
+                                       "value": round(4096 * S * S / (bf_ + bb_), 1), "unit": "Mpixels/s (kernel time)"}
+            del big, o
         if world == 1 and not args.no_cpu_baseline:
             res["unfold_path_same_gpu"] = unfold_on_gpu(args, dev)
             res["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)

@@ -155,6 +155,12 @@ uint64_t nfp_launch_count(void);
  * copied into a buffer of the calling thread. */
 const char* nfp_last_variant(void);
 
+/* Telemetry: the NEXT forward / backward kernel this process launches is bracketed by the two hipEvent_t
+ * (hipExtLaunchKernel: recorded at the kernel's own start and end on the device, as a profiler's kernel trace
+ * would) — per-kernel durations without a profiler and without inter-kernel gaps.  One shot; pass NULLs to
+ * disarm.  bench.py quotes its roofline on these. */
+void nfp_time_next_launch(void* start_event, void* stop_event);
+
 /* Test hook: re-read the NFP_* A/B switches (NFP_FORCE_GENERIC, NFP_FWD_SCALAR,
  * NFP_BWD_ATOMIC, NFP_BWD_BANDS, NFP_MFMA, NFP_FWD_BAND) from the environment.  They are
  * otherwise read once, when the library is loaded. */

@@ -19,7 +19,7 @@ F32, BF16 = 0, 1
 
 EXPORTS = ["nfp_abi_version", "nfp_last_error", "nfp_output_shape", "nfp_saved_floats", "nfp_forward",
            "nfp_backward", "nfp_pool_supported", "nfp_pool_forward", "nfp_pool_backward", "nfp_launch_count",
-           "nfp_last_variant", "nfp_plan", "nfp_reload_env", "nfp_workspace_bytes", "nfp_workspace_init"]
+           "nfp_last_variant", "nfp_plan", "nfp_reload_env", "nfp_workspace_bytes", "nfp_workspace_init", "nfp_time_next_launch"]
 
 
 class NfpDesc(ctypes.Structure):
@@ -59,6 +59,8 @@ def load():
     L.nfp_last_variant.restype = ctypes.c_char_p
     L.nfp_launch_count.restype = ctypes.c_uint64
     L.nfp_reload_env.restype = None
+    L.nfp_time_next_launch.argtypes = [vp, vp]
+    L.nfp_time_next_launch.restype = None
     L.nfp_plan.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_char_p, ctypes.c_int32]
     L.nfp_plan.restype = ctypes.c_int
     L.nfp_output_shape.argtypes = [dp, i32p, i32p, i32p]

@@ -19,7 +19,10 @@
 
 namespace nfp {
 
-constexpr int kBandT = 512;  // threads per workgroup
+#ifndef NFP_BAND_T
+#define NFP_BAND_T 512
+#endif
+constexpr int kBandT = NFP_BAND_T;  // threads per workgroup
 constexpr int kBandRB = 3;   // NCHW staging: 4-pixel x 4-channel blocks per thread per chunk
 constexpr int kBandRN = 6;   // channels-last staging: slots per thread per chunk
 

@@ -4,6 +4,7 @@
 // autograd backward.  gfx950 only; no CPU path lives here — the library fails
 // loudly (NFP_E_HIP / NFP_E_UNSUPPORTED) rather than fall back.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <atomic>
@@ -35,6 +36,7 @@ thread_local char t_variant_out[64] = "";
 std::mutex g_variant_mu;
 char g_variant_last[64] = "";
 std::atomic<uint64_t> g_launches{0};
+std::atomic<void*> g_time_start{nullptr}, g_time_stop{nullptr};  // nfp_time_next_launch (process-wide: backward launches from autograd's thread)
 
 void publish_variant() {
   std::lock_guard<std::mutex> lock(g_variant_mu);
@@ -185,7 +187,15 @@ int launch(const char* name, K kernel, dim3 grid, dim3 block, size_t lds, hipStr
     return NFP_OK;
   }
   if (int rc = set_lds(kernel, lds)) return rc;
-  hipLaunchKernelGGL(kernel, grid, block, lds, st, args...);
+  // telemetry (nfp_time_next_launch): bracket this one kernel with the caller's events — recorded by the command
+  // processor at the kernel's own start and end, like a profiler's kernel trace
+  hipEvent_t ev0 = name[0] != '#' ? (hipEvent_t)g_time_start.exchange(nullptr) : nullptr;
+  if (ev0 != nullptr) {
+    hipEvent_t ev1 = (hipEvent_t)g_time_stop.exchange(nullptr);
+    hipExtLaunchKernelGGL(kernel, grid, block, lds, st, ev0, ev1, 0, args...);
+  } else {
+    hipLaunchKernelGGL(kernel, grid, block, lds, st, args...);
+  }
   if (name[0] != '#') g_launches++;  // ('#': one-time setup kernels, not part of a forward / backward)
   return hip_ok(hipGetLastError(), name);
 }
@@ -721,6 +731,10 @@ const char* nfp_last_variant(void) {
   return t_variant_out;
 }
 void nfp_reload_env(void) { read_env(); }
+void nfp_time_next_launch(void* start_event, void* stop_event) {
+  g_time_stop.store(stop_event);
+  g_time_start.store(start_event);
+}
 uint64_t nfp_launch_count(void) { return g_launches.load(); }
 
 int nfp_output_shape(const nfp_desc* d, int32_t* N, int32_t* Ho, int32_t* Wo) {

@@ -7,7 +7,7 @@ mkdir -p gpurun_out/prof_$tag
 export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$tag -o trace -- \
-  python3 bench.py --no-cpu-baseline "$@" > gpurun_out/prof_$tag/bench.log 2>&1
+  python3 bench.py --no-cpu-baseline --no-extras "$@" > gpurun_out/prof_$tag/bench.log 2>&1
 rc=$?
 echo "rocprof rc=$rc"; tail -n 3 gpurun_out/prof_$tag/bench.log
 find gpurun_out/prof_$tag -name '*stats*' | head

@@ -8,7 +8,7 @@ export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   out=gpurun_out/pmc_$c; rm -rf $out; mkdir -p $out
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out -o pmc -- \
-    python3 bench.py --no-cpu-baseline --steps 20 --warmup 5 "$@" > $out/bench.log 2>&1
+    python3 bench.py --no-cpu-baseline --no-extras --steps 20 --warmup 5 "$@" > $out/bench.log 2>&1
   echo "$c rc=$?"
 done
 python3 - <<'PY'
@@ -46,9 +46,9 @@ key = bench.workload_key(bench.parse())
 one = json.load(open("gpurun_out/traffic.json"))
 path = "profiles/traffic_latest.json"
 allw = json.load(open(path)) if os.path.exists(path) else {"note": one["note"]}
+if allw.get("source_hash") != bench.source_hash():   # profiles of other kernel sources are stale: start over
+    allw = {"note": one["note"], "source_hash": bench.source_hash()}
 allw.setdefault("workloads", {})[key] = one["kernels"]
-if "kernels" in allw and key == "64x512x7x7 k3 cosine f32":
-    allw["kernels"] = one["kernels"]
 json.dump(allw, open("gpurun_out/traffic_workloads.json", "w"), indent=1)
 print("merged", key, "->", "gpurun_out/traffic_workloads.json (copy to profiles/traffic_latest.json)")
 PY
