@@ -171,10 +171,24 @@ __global__ void __launch_bounds__(kBandT) fwd_band(const KP g, const void* __res
     red[gl * NV + NF * Ps + lp] = nrm;
   }
   __syncthreads();
-  for (int i = t; i < NV; i += T) {
+  // value i is summed by S adjacent lanes (S = 1, 2 or 4: as many as the workgroup has to spare), lane `part` taking
+  // groups part, part + S, ...; the partial sums are joined by a fixed xor tree, so the order never varies
+  const int S = NV * 4 <= T ? 4 : (NV * 2 <= T ? 2 : 1), sh = S == 4 ? 2 : (S == 2 ? 1 : 0);
+  for (int i0 = 0; i0 < NV; i0 += T >> sh) {
+    const int i = i0 + (t >> sh), part = t & (S - 1);
     float s = 0.f;
-    for (int gg = 0; gg < G; ++gg) s += red[gg * NV + i];
-    Tt[i] = s;
+    const float* col = red + min(i, NV - 1);
+    for (int gg = part; gg < G; gg += 4 * S) {  // four reads in flight, added in a fixed order
+      const float v0 = col[gg * NV];
+      const float v1 = gg + S < G ? col[(gg + S) * NV] : 0.f;
+      const float v2 = gg + 2 * S < G ? col[(gg + 2 * S) * NV] : 0.f;
+      const float v3 = gg + 3 * S < G ? col[(gg + 3 * S) * NV] : 0.f;
+      s += (v0 + v1) + (v2 + v3);
+    }
+    // quad_perm lane exchanges (DPP: no LDS round trip): lane ^ 1, then lane ^ 2
+    if (S >= 2) s += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s), 0xB1, 0xF, 0xF, false));
+    if (S >= 4) s += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s), 0x4E, 0xF, 0xF, false));
+    if (i < NV && part == 0) Tt[i] = s;
   }
   __syncthreads();
   NFP_STAMP(4);

@@ -25,6 +25,7 @@
 // thread in a fixed order, so the result is bitwise reproducible and no atomics are used;
 // the padding adjoint is folded into Wm.  Then one pass: read x slab, write grad_x.
 #pragma once
+#include <type_traits>
 #include "nfp_tables.h"
 
 namespace nfp {
@@ -199,6 +200,41 @@ __device__ __forceinline__ void stage_store(const Staged<true>& s, float4* slab,
   for (int k = 0; k < kRN; ++k) {
     const int cq = gl + k * g.G;
     if (active && cq < ncq) slab[cq * ((g.P + 3) & ~3) + swz(p)] = s.v[k];
+  }
+}
+
+// NCHW staging without tail pixels (backward): ceil(P / 4) blocks per channel row; the last block of a row whose
+// length is not a multiple of 4 starts at P - 4 instead and overlaps its predecessor (the same values are written
+// twice).  No clamped tail loads: at P = 49 those were 8 of a thread's 20 load instructions, for 32 useful lanes.
+struct StagedOvl {
+  float4 blk[kRB][4];
+};
+template <bool BF>
+__device__ __forceinline__ void stage_load_ovl(StagedOvl& s, Rsrc x, const KP& g, int c0, int ncq, int t, int T) {
+  const int P = g.P, NQb = (P + 3) >> 2, nblk = ncq * NQb;
+#pragma unroll
+  for (int r = 0; r < kRB; ++r) {
+    const int i = min(t + r * T, nblk - 1);
+    const int cq = fdivi(i, NQb), pq = i - cq * NQb;
+    const int e = (c0 + 4 * cq) * P + min(4 * pq, P - 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s.blk[r][j] = load_px4<BF>(x, e, j * P);
+  }
+}
+__device__ __forceinline__ void stage_store_ovl(const StagedOvl& s, float4* slab, const KP& g, int ncq, int t, int T) {
+  const int P = g.P, NQb = (P + 3) >> 2, nblk = ncq * NQb, Pp = (P + 3) & ~3;
+#pragma unroll
+  for (int r = 0; r < kRB; ++r) {
+    const int i = t + r * T;
+    if (i < nblk) {
+      const int cq = fdivi(i, NQb), pq = i - cq * NQb;
+      const int ps = min(4 * pq, P - 4);
+      float4* d = slab + cq * Pp;
+      d[swz(ps)] = make_float4(s.blk[r][0].x, s.blk[r][1].x, s.blk[r][2].x, s.blk[r][3].x);
+      d[swz(ps + 1)] = make_float4(s.blk[r][0].y, s.blk[r][1].y, s.blk[r][2].y, s.blk[r][3].y);
+      d[swz(ps + 2)] = make_float4(s.blk[r][0].z, s.blk[r][1].z, s.blk[r][2].z, s.blk[r][3].z);
+      d[swz(ps + 3)] = make_float4(s.blk[r][0].w, s.blk[r][1].w, s.blk[r][2].w, s.blk[r][3].w);
+    }
   }
 }
 
@@ -654,7 +690,18 @@ __global__ void __launch_bounds__(GEMM ? 1024 : kBwdThreads) bwd_fast(const KP g
   // and this image's grad_out / out / norms first (small, L2-resident), then the x chunk, so that the pair
   // arithmetic runs while x streams in.  One table entry / pair per thread and round, the next round's loads in
   // flight during the current round's arithmetic.
-  const int NE = P * K2, NO = N * P;
+  // k = 5 (25 slots per pixel, about five entries per thread): only the centre slot and the NF slots AFTER it are
+  // gathered — the pairs that link r with the pixel t under slot j are the pairs that link t with r under its slot
+  // K2-1-j, so each sum is stored twice.  k = 3 has fewer entries than threads: every slot is gathered by its own
+  // thread.
+  constexpr bool SYM = R >= 2;
+  constexpr int NJ = SYM ? Win<R>::NF + 1 : K2;
+  const int NE = P * NJ, NO = N * P;
+  auto entry_of = [&](int e2, int& r, int& j) {  // gathered entry e2 -> (pixel, slot); returns its table row
+    r = fdivi(e2, NJ);
+    j = (SYM ? K2 / 2 : 0) + e2 - r * NJ;
+    return r * K2 + j;
+  };
   uint4 rw0, rw1;
   uint32_t tqv;
   auto rows_load = [&](int e) {
@@ -667,7 +714,10 @@ __global__ void __launch_bounds__(GEMM ? 1024 : kBwdThreads) bwd_fast(const KP g
     gv = POOL ? gnfpm[(long long)b * N + fdivi(o, P)] * g.invP : ldx(gob, o, DT);
     ov = ldx(outb, o, DT);
   };
-  rows_load(min(t, NE - 1));
+  {
+    int r_, j_;
+    rows_load(entry_of(min(t, NE - 1), r_, j_));
+  }
   pair_load(min(t, NO - 1));
   const float nrm = (M == NFP_COSINE) ? saved[(long long)b * P + min(t, P - 1)] : 0.f;
   uint4 bo[L_BRQ<R>::v];  // this pixel's window offsets (phase B)
@@ -677,8 +727,20 @@ __global__ void __launch_bounds__(GEMM ? 1024 : kBwdThreads) bwd_fast(const KP g
     for (int u = 0; u < L_BRQ<R>::v; ++u) bo[u] = bot[u];
   }
   __builtin_amdgcn_sched_barrier(0);  // keep these (small, needed first) loads ahead of the x chunk
-  Staged<NHWC> st;
-  if constexpr (!GEMM) stage_issue<BF, NHWC>(st, xb, g, cb0, min(g.Cc, cb1 - cb0) >> 2, t, T, p, gl, active);
+  typename std::conditional<NHWC, Staged<true>, StagedOvl>::type st;
+  auto x_issue = [&](int c0, int ncq) {
+    if constexpr (NHWC)
+      stage_load<BF>(st, xb, g, c0, ncq, p, gl, active);
+    else
+      stage_load_ovl<BF>(st, xb, g, c0, ncq, t, T);
+  };
+  auto x_commit = [&](int ncq) {
+    if constexpr (NHWC)
+      stage_store(st, slab, g, ncq, p, gl, active);
+    else
+      stage_store_ovl(st, slab, g, ncq, t, T);
+  };
+  if constexpr (!GEMM) x_issue(cb0, min(g.Cc, cb1 - cb0) >> 2);
   // nothing that consumes a loaded value may be scheduled above this line (hipcc otherwise hoists consumers into
   // the load sequence and stalls the remaining loads behind a vmcnt wait)
   __builtin_amdgcn_sched_barrier(0);
@@ -701,15 +763,25 @@ __global__ void __launch_bounds__(GEMM ? 1024 : kBwdThreads) bwd_fast(const KP g
     ipn[t] = ip;
     dfn[t] = nrm > 0.f ? -ip * __builtin_amdgcn_rcpf(nrm) : 0.f;
   }
+  if constexpr (SYM) {
+    for (int i = t; i < P * K2; i += T) {  // slots before the centre whose pixel lies outside the image keep this 0
+      Wt[i] = 0.f;
+      Dt[i] = 0.f;
+    }
+  }
   __syncthreads();
   NFP_STAMP(2);
   // A2: window entry (r, j) = the sum of the pairs that link r with the pixel under slot j, listed by the table
-  for (int e = t; e < NE; e += T) {
+  for (int e2 = t; e2 < NE; e2 += T) {
     const uint4 r0 = rw0, r1 = rw1;
     const uint32_t tqc = tqv;
-    if (e + T < NE) rows_load(e + T);
-    const int r = fdivi(e, K2), j = e - r * K2;
-    float S = 0.f, Dj = 0.f, wv;
+    int r, j;
+    const int e = entry_of(e2, r, j);
+    if (e2 + T < NE) {
+      int r_, j_;
+      rows_load(entry_of(e2 + T, r_, j_));
+    }
+    float S = 0.f, Dj = 0.f, Dm = 0.f, wv;  // Dj: diagonal term for r, Dm: for the pixel t on the other end
     if (j != K2 / 2) {
       auto take = [&](uint32_t ent) {  // one list entry, predicated (the lists are packed: live entries first)
         const bool on = ent != 0xFFFFu;
@@ -721,34 +793,40 @@ __global__ void __launch_bounds__(GEMM ? 1024 : kBwdThreads) bwd_fast(const KP g
         } else {
           const float cv = CC[o];
           S += on ? cv : 0.f;
-          Dj += (on && (g.diff || (ent & 0x8000u))) ? cv : 0.f;  // 'Norm' quirk: neighbour-role terms only
+          Dj += (on && (g.diff || (ent & 0x8000u))) ? cv : 0.f;   // 'Norm' quirk: only the pair's NEIGHBOUR is pulled
+          Dm += (on && (g.diff || !(ent & 0x8000u))) ? cv : 0.f;  // (bit 15: r is the neighbour of this pair)
         }
       };
       auto live = [&](uint32_t w2) { return __ballot((w2 & 0xFFFFu) != 0xFFFFu) != 0; };  // wave-uniform
+      // k = 3 (one entry per thread): the first piece in one batch of LDS reads — a branch per pair of entries
+      // costs an LDS round trip each; k = 5 (ten entries per thread, most of them two links long): skip the rest
       take(r0.x & 0xFFFFu);
       take(r0.x >> 16);
-      if (live(r0.y)) {
+      if (R == 1 || live(r0.y)) {
         take(r0.y & 0xFFFFu);
         take(r0.y >> 16);
-        if (live(r0.z)) {
-          take(r0.z & 0xFFFFu);
-          take(r0.z >> 16);
-          take(r0.w & 0xFFFFu);
-          take(r0.w >> 16);
-          if (LQ > 1 && live(r1.x)) {
-            take(r1.x & 0xFFFFu);
-            take(r1.x >> 16);
-            take(r1.y & 0xFFFFu);
-            take(r1.y >> 16);
-            take(r1.z & 0xFFFFu);
-            take(r1.z >> 16);
-            take(r1.w & 0xFFFFu);
-            take(r1.w >> 16);
-          }
-        }
+        take(r0.z & 0xFFFFu);
+        take(r0.z >> 16);
+        take(r0.w & 0xFFFFu);
+        take(r0.w >> 16);
+      }
+      if (LQ > 1 && live(r1.x)) {
+        take(r1.x & 0xFFFFu);
+        take(r1.x >> 16);
+        take(r1.y & 0xFFFFu);
+        take(r1.y >> 16);
+        take(r1.z & 0xFFFFu);
+        take(r1.z >> 16);
+        take(r1.w & 0xFFFFu);
+        take(r1.w >> 16);
       }
       const int tt = tqc == 0xFFFFu ? r : (int)tqc;
       wv = M == NFP_COSINE ? ipn[r] * ipn[tt] * S : (g.diff ? -S : 0.f);
+      if (SYM && tqc != 0xFFFFu) {  // the same pairs, seen from t
+        const int em = tt * K2 + (K2 - 1 - j);
+        Wt[em] = wv;
+        Dt[em] = M == NFP_COSINE ? Dj : Dm;
+      }
     } else {
       // centre slot: its row carries the pixel's two tap masks instead of links (zero-padded taps, self pairs)
       uint32_t zm = r0.x, sm = r0.y;
@@ -777,11 +855,7 @@ __global__ void __launch_bounds__(GEMM ? 1024 : kBwdThreads) bwd_fast(const KP g
   // (the pair values stay readable until the barrier: with g.early the slab does not overlap them, so the x chunk
   // is committed here, while slower wavefronts still gather)
   if constexpr (!GEMM) {
-    if (g.early) {
-#pragma unroll
-      for (int part = 0; part < kRB; ++part)
-        stage_commit<BF, NHWC>(st, slab, g, min(g.Cc, cb1 - cb0) >> 2, t, T, p, gl, active, part);
-    }
+    if (g.early) x_commit(min(g.Cc, cb1 - cb0) >> 2);
   }
   __syncthreads();
   NFP_STAMP(3);
@@ -825,11 +899,10 @@ __global__ void __launch_bounds__(GEMM ? 1024 : kBwdThreads) bwd_fast(const KP g
     const int ncq = min(g.Cc, cb1 - c0) >> 2;
     if (c0 > cb0) {
       __syncthreads();
-      stage_issue<BF, NHWC>(st, xb, g, c0, ncq, t, T, p, gl, active);
+      x_issue(c0, ncq);
     }
     if (c0 > cb0 || !g.early) {
-#pragma unroll
-      for (int part = 0; part < kRB; ++part) stage_commit<BF, NHWC>(st, slab, g, ncq, t, T, p, gl, active, part);
+      x_commit(ncq);
       __syncthreads();
     }
     NFP_STAMP(5);

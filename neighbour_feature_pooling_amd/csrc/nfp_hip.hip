@@ -506,10 +506,13 @@ int even_groups(int ncq, int gmax) {
 }
 
 // channels per LDS chunk: bounded by the slab budget and by what one staging round-set can carry
-int chunk_channels(const KP& g, int total, int T, int G, bool nhwc, int budget) {
+int chunk_channels(const KP& g, int total, int T, int G, bool nhwc, int budget, bool overlap_blocks = false) {
   int ncq = budget / (((g.P + 3) & ~3) * 16);
   if (nhwc) {
     if (ncq > kRN * G) ncq = kRN * G;
+  } else if (overlap_blocks) {  // backward: ceil(P/4) blocks per channel row, no tail pixels (nfp_fast.h: StagedOvl)
+    const int NQb = (g.P + 3) >> 2;
+    if (ncq > (kRB * T) / NQb) ncq = (kRB * T) / NQb;
   } else {
     const int NQ = g.P >> 2, PT = g.P & 3;
     if (NQ > 0 && ncq > (kRB * T) / NQ) ncq = (kRB * T) / NQ;
@@ -626,10 +629,10 @@ int launch_bwd_fast_t(KP g, const void* x, const void* go, const void* out, cons
   int T = ((g.P * g.G + 63) / 64) * 64;
   // large batches (one workgroup per image, several images per CU over time): fewer, larger chunks win
   const int bbudget = (S == 1 && g.B > 256) ? 2 * kSlabBudgetBwd : kSlabBudgetBwd;
-  g.Cc = chunk_channels(g, g.Cwg, T, g.G, NHWC, bbudget);
+  g.Cc = chunk_channels(g, g.Cwg, T, g.G, NHWC, bbudget, true);
   g.G = even_groups(g.Cc / 4, g.G);
   T = ((g.P * g.G + 63) / 64) * 64;
-  g.Cc = chunk_channels(g, g.Cwg, T, g.G, NHWC, bbudget);
+  g.Cc = chunk_channels(g, g.Cwg, T, g.G, NHWC, bbudget, true);
   const size_t fixed = bwd_fixed_bytes(g, K2), pairs = bwd_pair_bytes(g, M, N);
   const size_t slab = (size_t)(g.Cc / 4) * ((g.P + 3) & ~3) * 16;
   g.early = fixed + pairs + slab <= kEarlyBudget ? 1 : 0;
