@@ -467,8 +467,13 @@ def main():
     res = None
     if rank == 0:
         timer = KernelTimer(L)
-        tf, tb, tf_med, tb_med = rot.kernel_events(timer, stream)   # per-kernel HIP events on the launch stream
-        tf_graph, tb_graph = rot.kernel_times(stream)               # and: graph-replayed launches / count (gaps included)
+        # Per-kernel durations of the TIMED REGION's launches: HIP events on the launch stream around graph-replayed
+        # launches — a graph of forwards, and a graph of steps minus it.  (rocprofv3's kernel trace of a graph replay
+        # stamps a kernel's start where its predecessor ends, so its per-kernel averages partition the step the same
+        # way.)  Also reported: each launch bracketed by its own event pair in eager order (kernel start to kernel end
+        # on an otherwise idle GPU, nfp_time_next_launch).
+        tf, tb = rot.kernel_times(stream)
+        tf_ev, tb_ev, tf_med, tb_med = rot.kernel_events(timer, stream)
         dom_bytes, dom_t, dom, dom_variant = ((rot.bb, tb, "backward", bwd_variant) if tb >= tf else
                                               (rot.fb, tf, "forward", fwd_variant))
         achieved = dom_bytes / (dom_t * 1e-6) / 1e9
@@ -502,25 +507,26 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_us": round(dom_t, 3)},
-            "kernels": {"how": "forward_us / backward_us: mean over 2 passes of the rotating sets of each launch's own HIP "
-                               "event pair (hipExtLaunchKernel: kernel start to kernel end, what rocprofv3's kernel "
-                               "trace reports); *_graph_us: K graph-replayed launches / K, inter-kernel gaps included",
+            "kernels": {"how": "forward_us: HIP events around a graph of rotating forwards / launches; backward_us: the same "
+                               "around a graph of rotating steps, minus forward_us (launch boundaries included, as in "
+                               "the timed region and in rocprofv3's trace of a graph replay); *_eager_event_us: mean / "
+                               "median of each launch's own hipExtLaunchKernel event pair, eager order, idle GPU between",
                         "forward_us": round(tf, 3), "backward_us": round(tb, 3),
-                        "forward_median_us": round(tf_med, 3), "backward_median_us": round(tb_med, 3),
-                        "forward_graph_us": round(tf_graph, 3), "backward_graph_us": round(tb_graph, 3),
+                        "forward_eager_event_us": round(tf_ev, 3), "backward_eager_event_us": round(tb_ev, 3),
+                        "forward_eager_event_median_us": round(tf_med, 3), "backward_eager_event_median_us": round(tb_med, 3),
                         "forward_variant": fwd_variant, "backward_variant": bwd_variant,
                         "fwd_bytes": rot.fb, "bwd_bytes": rot.bb,
                         "fwd_GBs": round(rot.fb / tf / 1e3, 1), "bwd_GBs": round(rot.bb / tb / 1e3, 1)},
         }
         if extras:
-            tf_hot, tb_hot, _, _ = hot.kernel_events(timer, stream, rounds=50)
+            tf_hot, tb_hot = hot.kernel_times(stream, reps=50)
             res["cache_resident"] = {"what": "the same K steps on ONE buffer set (inputs served by L2 / Infinity Cache)",
                                      "value": round(px_per_step * args.steps / elapsed_hot / 1e6, 3),
                                      "ms_per_step": round(elapsed_hot / args.steps * 1e3, 6),
                                      "forward_us": round(tf_hot, 3), "backward_us": round(tb_hot, 3),
                                      "fwd_GBs": round(rot.fb / tf_hot / 1e3, 1), "bwd_GBs": round(rot.bb / tb_hot / 1e3, 1)}
             rl = Workload(args, dev, rank, relu=True)                       # what a ResNet trunk emits: x >= 0, ~50 % zeros
-            rf, rbk, _, _ = rl.kernel_events(timer, stream)
+            rf, rbk = rl.kernel_times(stream)
             res["relu_input"] = {"what": "the same workload with x = relu(randn): non-negative, about half zeros",
                                  "forward_us": round(rf, 3), "backward_us": round(rbk, 3),
                                  "value": round(px_per_step / (rf + rbk), 3), "unit": "Mpixels/s (kernel time)"}
