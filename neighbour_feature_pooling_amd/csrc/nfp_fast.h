@@ -470,7 +470,7 @@ __global__ void __launch_bounds__(MAXT) fwd_fast(const KP g, const void* __restr
 //      step keep 16 significand bits of every weight; the inputs themselves carry 8)
 // and the same two LDS images serve both orientations: A = Xt, B = Wd gives D[channel][pixel] (lanes along
 // pixels: coalesced NCHW stores), A = Wd, B = Xt gives D[pixel][channel] (channels-last stores).
-// Row tiles are processed two at a time (Wd of all of them does not fit next to Xt at config 5's shape).
+// Row tiles are processed a few at a time (Wd of all of them does not fit next to Xt at config 5's shape: g.Tc).
 __device__ __forceinline__ int odd_up(int v) { return v | 1; }
 
 template <int R, bool NHWC>
@@ -550,8 +550,9 @@ __device__ __forceinline__ void bwd_gemm_phase(const KP& g, const float* Wt, uin
   }
 
   const int nct = ncw >> 5;
-  for (int i0 = 0; i0 < nt; i0 += 2) {
-    const int nrt = min(2, nt - i0);
+  const int RT = g.Tc;  // row tiles per round: as many as fit in LDS next to Xt (launcher), at least 2
+  for (int i0 = 0; i0 < nt; i0 += RT) {
+    const int nrt = min(RT, nt - i0);
     __syncthreads();  // Xt staged / previous Wd consumed
     // ---- Wd for row tiles i0, i0 + 1: zero, then scatter the window slots of each row -----------------------
     for (int i = t; i < nrt * 2 * 32 * wq; i += T) Wd[i] = make_uint4(0, 0, 0, 0);
@@ -673,7 +674,6 @@ __global__ void __launch_bounds__(GEMM ? 1024 : kBwdThreads) bwd_fast(const KP g
   const int cb0 = blockIdx.y * g.Cwg, cb1 = min(g.C, cb0 + g.Cwg);
   const int gl = fast_div(t, g.invP), p = t - gl * P;
   const bool active = gl < g.G;
-  constexpr int DT = BF ? NFP_BF16 : NFP_F32;
   constexpr int ES = BF ? 2 : 4;
   const Rsrc xb = make_rsrc((const char*)x + (long long)b * g.sB * ES, (long long)g.C * P * ES);  // wave-uniform
   const Rsrc gxb = make_rsrc((char*)gx + (long long)b * g.gB * ES, (long long)g.C * P * ES);
@@ -709,16 +709,23 @@ __global__ void __launch_bounds__(GEMM ? 1024 : kBwdThreads) bwd_fast(const KP g
     rw1 = lnk[(long long)e * LQ + LQ - 1];  // (unconditional: the same piece again when a row is one piece)
     tqv = tqt[e];
   };
-  float gv, ov;
-  auto pair_load = [&](int o) {
-    gv = POOL ? gnfpm[(long long)b * N + fdivi(o, P)] * g.invP : ldx(gob, o, DT);
-    ov = ldx(outb, o, DT);
+  // grad_out / out of this image, 16 bytes per thread and round: VP consecutive pairs (N is a multiple of 8, so
+  // N*P values are whole 16-byte pieces and every image's maps start on one)
+  constexpr int VP = BF ? 8 : 4;
+  uint4 gq, oq;
+  auto pair_load = [&](int o) {  // o: first pair of the piece
+    if constexpr (!POOL) gq = *(const uint4*)((const char*)gob + (long long)o * ES);
+    oq = *(const uint4*)((const char*)outb + (long long)o * ES);
+  };
+  auto pair_value = [&](const uint4& q, int k) {  // element k of a 16-byte piece
+    const uint32_t wd = ((const uint32_t*)&q)[BF ? k >> 1 : k];
+    return BF ? __uint_as_float(k & 1 ? wd & 0xFFFF0000u : wd << 16) : __uint_as_float(wd);
   };
   {
     int r_, j_;
     rows_load(entry_of(min(t, NE - 1), r_, j_));
   }
-  pair_load(min(t, NO - 1));
+  pair_load(min(t * VP, NO - VP));
   const float nrm = (M == NFP_COSINE) ? saved[(long long)b * P + min(t, P - 1)] : 0.f;
   uint4 bo[L_BRQ<R>::v];  // this pixel's window offsets (phase B)
   if constexpr (!GEMM) {
@@ -746,16 +753,21 @@ __global__ void __launch_bounds__(GEMM ? 1024 : kBwdThreads) bwd_fast(const KP g
   __builtin_amdgcn_sched_barrier(0);
   NFP_STAMP(1);
   // A1: per-pair values, in the memory order of grad_out / out
-  for (int o = t; o < NO; o += T) {
-    const float gc = gv, oc = ov;
-    if (o + T < NO) pair_load(o + T);
-    if (M == NFP_COSINE) {
-      const float s = g.similarity ? oc : 1.f - oc;
-      const float sg = g.similarity ? gc : -gc;
-      AD[o] = make_float2(sg, sg * s);
-    } else {
-      const float d = fabsf(oc);
-      CC[o] = d == 0.f ? 0.f : (g.similarity ? -gc : gc) * __builtin_amdgcn_rcpf(d);
+  for (int o = t * VP; o < NO; o += T * VP) {
+    const uint4 gc4 = gq, oc4 = oq;
+    if (o + T * VP < NO) pair_load(o + T * VP);
+#pragma unroll
+    for (int k = 0; k < VP; ++k) {
+      const float oc = pair_value(oc4, k);
+      const float gc = POOL ? gnfpm[(long long)b * N + fdivi(o + k, P)] * g.invP : pair_value(gc4, k);
+      if (M == NFP_COSINE) {
+        const float s = g.similarity ? oc : 1.f - oc;
+        const float sg = g.similarity ? gc : -gc;
+        AD[o + k] = make_float2(sg, sg * s);
+      } else {
+        const float d = fabsf(oc);
+        CC[o + k] = d == 0.f ? 0.f : (g.similarity ? -gc : gc) * __builtin_amdgcn_rcpf(d);
+      }
     }
   }
   if (M == NFP_COSINE && t < P) {
@@ -763,11 +775,9 @@ __global__ void __launch_bounds__(GEMM ? 1024 : kBwdThreads) bwd_fast(const KP g
     ipn[t] = ip;
     dfn[t] = nrm > 0.f ? -ip * __builtin_amdgcn_rcpf(nrm) : 0.f;
   }
-  if constexpr (SYM) {
-    for (int i = t; i < P * K2; i += T) {  // slots before the centre whose pixel lies outside the image keep this 0
-      Wt[i] = 0.f;
-      Dt[i] = 0.f;
-    }
+  if constexpr (SYM) {  // slots before the centre whose pixel lies outside the image keep this 0 (Wt and Dt are adjacent)
+    for (int i = t; i < (2 * P * K2) >> 2; i += T) ((float4*)Wt)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (t < ((2 * P * K2) & 3)) Wt[((2 * P * K2) & ~3) + t] = 0.f;
   }
   __syncthreads();
   NFP_STAMP(2);

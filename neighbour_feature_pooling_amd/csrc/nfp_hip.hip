@@ -690,8 +690,16 @@ int launch_bwd_gemm_t(KP g, const void* x, const void* go, const void* out, cons
   g.Cc = g.Cwg;
   const int band = g.R * g.W + g.R, KW = (32 + 2 * band + 30) >> 4;
   const size_t xq = (size_t)((((g.P + 15) >> 4 << 1) + 1) | 1), wq = (size_t)((2 * KW + 1) | 1);
-  const size_t images = ((size_t)g.Cwg * xq + 2 * 2 * 32 * wq) * 16;
-  const size_t lds = bwd_fixed_bytes(g, K2) + std::max(bwd_pair_bytes(g, M, N), images);
+  // row tiles whose densified weights sit in LDS together (fewer rounds of zero / scatter / barrier): all that fit
+  const int nt = (g.P + 31) / 32;
+  const size_t xt = (size_t)g.Cwg * xq * 16, wd1 = (size_t)2 * 32 * wq * 16, fixed = bwd_fixed_bytes(g, K2);
+  int rt = fixed + xt < (size_t)kLdsMax ? (int)(((size_t)kLdsMax - fixed - xt) / wd1) : 0;
+  rt = std::min(rt, nt);
+  if (rt >= 2 && rt < nt) rt = (nt + ((nt + rt - 1) / rt) - 1) / ((nt + rt - 1) / rt);  // even rounds
+  if (rt < std::min(2, nt)) return kNotApplicable;
+  g.Tc = rt;
+  const size_t images = xt + (size_t)rt * wd1;
+  const size_t lds = fixed + std::max(bwd_pair_bytes(g, M, N), images);
   g.early = 0;
   if (lds > (size_t)kLdsMax) return kNotApplicable;
   snprintf(g_variant, sizeof(g_variant), "bwd_fast<R%d,%s,bf16,%s,mfma>", R, M == NFP_COSINE ? "cos" : "l2",
