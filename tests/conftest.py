@@ -32,6 +32,37 @@ def same_nan_pattern(a, ref):
     return np.array_equal(np.isnan(a), np.isnan(ref))
 
 
+def golden_out_shape(g):
+    return tuple(g["out"].shape) if "out" in g else tuple(int(v) for v in g["out_shape"])
+
+
+def assert_matches_golden(out, gx, g, tol, tol_gx=None):
+    """`out` / `gx` (numpy, the case's full tensors; gx may be None) against a fixture of tests/golden/.  Small
+    tensors are stored in full; large ones as every 97th element plus per-image (gx) / per-map (out) sums and
+    absolute sums of the reference's tensor (cases.py: full_limit)."""
+    import cases as K
+    tol_gx = tol if tol_gx is None else tol_gx
+
+    def sampled(a, sample, s_ref, a_ref, axes, t):
+        assert rel_err(a.reshape(-1)[K.gx_sample_index(a.size)], sample) <= t
+        s = a.astype(np.float64).sum(axis=axes)
+        assert np.max(np.abs(s - s_ref) / a_ref) <= t
+
+    assert tuple(out.shape) == golden_out_shape(g)
+    if "out" in g:
+        assert same_nan_pattern(out, g["out"])
+        assert rel_err(np.nan_to_num(out), np.nan_to_num(g["out"])) <= tol
+    else:
+        sampled(out, g["out_sample"], g["out_sum"], g["out_abs_sum"], (2, 3), tol)
+    if gx is None:
+        return
+    if "gx" in g:
+        assert same_nan_pattern(gx, g["gx"])
+        assert rel_err(np.nan_to_num(gx), np.nan_to_num(g["gx"])) <= tol_gx
+    else:
+        sampled(gx, g["gx_sample"], g["gx_sum"], g["gx_abs_sum"], (1, 2, 3), tol_gx)
+
+
 @pytest.fixture(scope="session")
 def oracle_lib():
     import oracle

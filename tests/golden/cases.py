@@ -8,13 +8,13 @@ ctor = keyword arguments of NFPPooling(in_channels=C, **ctor)  (nfp.py:16-18).
 """
 import numpy as np
 
-FULL_GX_LIMIT = 131072  # store grad_x in full up to this many elements, else a strided sample
+FULL_GX_LIMIT = 131072  # store grad_x (and out) in full up to this many elements, else a strided sample
 SAMPLE_STRIDE = 97
 
 
-def case(name, shape, ctor, seed, kind="normal", tweak=None, go_kind="normal"):
+def case(name, shape, ctor, seed, kind="normal", tweak=None, go_kind="normal", full_limit=FULL_GX_LIMIT):
     return dict(name=name, shape=tuple(shape), ctor=dict(ctor), seed=seed, kind=kind, tweak=tweak,
-                go_kind=go_kind)
+                go_kind=go_kind, full_limit=full_limit)
 
 
 COS = dict(R=1, measure="cosine", padding=1)
@@ -59,6 +59,16 @@ CASES = [
                                                      padding_mode="replicate"), 49),
     case("geo_cos_k7", (1, 8, 9, 9), dict(R=3, measure="cosine", padding=3), 50),
     case("geo_cos_big_map", (1, 16, 40, 36), COS, 51),
+    # the five feature maps MobileNetV3_MultiStageNFP feeds NFP(R=1, cosine, padding=1) at a 224x224 input
+    # (texture_pooling.py:211-268; mobilenetv3_large_100 features_only: 16, 24, 40, 112, 960 channels)
+    case("ms_cos_112x112x16", (1, 16, 112, 112), COS, 52, kind="relu", full_limit=16384),
+    case("ms_cos_56x56x24", (1, 24, 56, 56), COS, 53, kind="relu", full_limit=16384),
+    case("ms_cos_28x28x40", (2, 40, 28, 28), COS, 54, kind="relu", full_limit=16384),
+    case("ms_cos_14x14x112", (2, 112, 14, 14), COS, 55, kind="relu", full_limit=16384),
+    case("ms_cos_7x7x960", (2, 960, 7, 7), COS, 56, kind="relu", full_limit=16384),
+    # the reference's default input_size: a 224x224 map (beyond one LDS channel slab)
+    case("geo_cos_224x224", (1, 4, 224, 224), COS, 57, full_limit=16384),
+    case("geo_l2_k5_160x160", (1, 4, 160, 160), L2K5, 58, full_limit=16384),
     # --- Norm variants (nfp.py:141-148, quirk at nfp.py:74) -------------------------------
     case("norm_p1_default", (2, 16, 7, 7), dict(R=1, measure="norm", padding=1), 60),
     case("norm_p3", (2, 16, 7, 7), dict(R=1, measure="norm", p=3, padding=1), 61),

@@ -14,7 +14,7 @@ import pytest
 import torch
 
 import cases as K
-from conftest import load_golden, nfp_switch, rel_err, same_nan_pattern
+from conftest import assert_matches_golden, golden_out_shape, load_golden, nfp_switch, rel_err, same_nan_pattern
 
 pytestmark = pytest.mark.gpu
 
@@ -81,17 +81,7 @@ def test_hip_matches_reference_golden(name, dev, variant):
     c = K.BY_NAME[name]
     g = load_golden(name)
     out, gx, _ = run_hip(c, dev)
-    assert out.shape == g["out"].shape
-    assert same_nan_pattern(out, g["out"])
-    assert rel_err(np.nan_to_num(out), np.nan_to_num(g["out"])) <= TOL
-    if "gx" in g:
-        assert same_nan_pattern(gx, g["gx"])
-        assert rel_err(np.nan_to_num(gx), np.nan_to_num(g["gx"])) <= TOL
-    else:
-        idx = K.gx_sample_index(gx.size)
-        assert rel_err(gx.reshape(-1)[idx], g["gx_sample"]) <= TOL
-        s = gx.astype(np.float64).sum(axis=(1, 2, 3))
-        assert np.max(np.abs(s - g["gx_sum"]) / g["gx_abs_sum"]) <= TOL
+    assert_matches_golden(out, gx, g, TOL)
 
 
 @pytest.mark.parametrize("name", [c["name"] for c in K.CASES if _supported(c)])
@@ -463,12 +453,12 @@ def test_c_abi_direct_calls_match_reference_golden(name, dev):
     d.sxB, d.sxC, d.sxH, d.sxW = x.stride()
     n, ho, wo = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
     assert L.nfp_output_shape(ctypes.byref(d), ctypes.byref(n), ctypes.byref(ho), ctypes.byref(wo)) == 0
-    assert (d.B, n.value, ho.value, wo.value) == g["out"].shape
-    out = torch.empty(g["out"].shape, device=dev)
+    assert (d.B, n.value, ho.value, wo.value) == golden_out_shape(g)
+    out = torch.empty(golden_out_shape(g), device=dev)
     saved = torch.empty(max(int(L.nfp_saved_floats(ctypes.byref(d))), 1), device=dev)
     stream = torch.cuda.current_stream().cuda_stream
     assert L.nfp_forward(ctypes.byref(d), x.data_ptr(), out.data_ptr(), saved.data_ptr(), stream) == 0, L.nfp_last_error()
-    go = torch.from_numpy(K.make_grad_out(c, g["out"].shape)).to(dev)
+    go = torch.from_numpy(K.make_grad_out(c, golden_out_shape(g))).to(dev)
     gx = torch.empty_like(x)
     assert L.nfp_backward(ctypes.byref(d), x.data_ptr(), go.data_ptr(), out.data_ptr(), saved.data_ptr(), gx.data_ptr(),
                           stream) == 0, L.nfp_last_error()
