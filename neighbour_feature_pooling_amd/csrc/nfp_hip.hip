@@ -21,7 +21,7 @@
 #include "nfp_band.h"
 #include "nfp_gather.h"
 #include "nfp_mfma.h"
-#include "nfp_generic.h"
+#include "nfp_direct.h"
 
 using namespace nfp;
 
@@ -82,16 +82,8 @@ int hip_ok(hipError_t e, const char* what) {
   return fail(NFP_E_HIP, "%s: %s", what, hipGetErrorString(e));
 }
 
-constexpr int kLdsBudgetFwd = 64 * 1024;  // bytes of x chunk per forward workgroup
-constexpr int kLdsBudgetBwd = 48 * 1024;  // bytes of x chunk (and as much again of grad) per backward workgroup
 constexpr int kLdsMax = 160 * 1024;
 constexpr int kNotApplicable = 1;  // internal: a hot-path launcher declined, use the generic kernels
-
-int floor_pow2(int v) {
-  int p = 1;
-  while (p * 2 <= v) p *= 2;
-  return p;
-}
 
 // Validate the descriptor the way nn.Conv2d / F.pad would and fill the kernel parameter block.
 int make_kp(const nfp_desc* d, KP* g) {
@@ -134,8 +126,10 @@ int make_kp(const nfp_desc* d, KP* g) {
   g->invNQ = 1.0f / (float)((g->P >> 2) > 0 ? (g->P >> 2) : 1);
   g->invPT = 1.0f / (float)((g->P & 3) > 0 ? (g->P & 3) : 1);
   g->inv_eps = 1.0f / g->eps;
-  if ((int64_t)g->P * 4 + 64 > kLdsMax)
-    return fail(NFP_E_UNSUPPORTED, "feature map %dx%d does not fit one LDS channel slab", d->H, d->W);
+  // index arithmetic of the general kernels: coordinates in 15 bits, pair indices in 31
+  if (d->H > 32767 || d->W > 32767 || (int64_t)g->P > (1 << 26) || (int64_t)g->N * g->O >= (1LL << 31) || d->B > 65535)
+    return fail(NFP_E_UNSUPPORTED, "feature map [%d,%d,%d,%d] with k = %d exceeds the index range of the kernels", d->B,
+                d->C, d->H, d->W, k);
   return NFP_OK;
 }
 
@@ -275,24 +269,10 @@ int launch_fwd_pairs(const KP& g, const void* x, void* out, float* saved, hipStr
 template <int M>
 int launch_fwd_generic(KP g, const void* x, void* out, float* saved, hipStream_t st) {
   if (int rc = launch_fwd_pairs<M>(g, x, out, saved, st); rc != kNotApplicable) return rc;
-  g.Cc = kLdsBudgetFwd / (g.P * 4);
-  if (g.Cc < 1) g.Cc = 1;
-  if (g.Cc > g.C) g.Cc = g.C;
-  if (g.O <= 1024) {
-    g.Ow = g.O;
-    g.G = floor_pow2(1024 / g.O);
-    if (g.G > 64) g.G = 64;
-    if (g.G > floor_pow2(g.C)) g.G = floor_pow2(g.C);
-  } else {
-    g.Ow = 1024;
-    g.G = 1;
-  }
-  int T = ((g.Ow * g.G + 63) / 64) * 64;
-  size_t lds = (size_t)g.Cc * g.P * 4;
-  if (lds > (size_t)kLdsMax) return fail(NFP_E_UNSUPPORTED, "forward: feature map %dx%d does not fit LDS", g.H, g.W);
-  dim3 grid(g.B, (g.O + g.Ow - 1) / g.Ow, (g.N + kGroup - 1) / kGroup);
-  snprintf(g_variant, sizeof(g_variant), "fwd_generic");
-  return launch("fwd_generic", fwd_generic<M>, grid, dim3(T), lds, st, g, x, out, saved);
+  // last resort (nfp_direct.h): no LDS tables, any map size
+  snprintf(g_variant, sizeof(g_variant), "fwd_direct");
+  return launch("fwd_direct", fwd_direct<M>, dim3((unsigned)((g.O + 255) / 256), (g.N + kGroup - 1) / kGroup, g.B), dim3(256),
+                0, st, g, x, out, saved);
 }
 
 // Gather-form backward (nfp_gather.h): tables + one slab of >= QB channel quads must fit in LDS and the
@@ -438,29 +418,10 @@ int launch_bwd_generic(KP g, const void* x, const void* go, const void* out, con
                        hipStream_t st) {
   if (int rc = launch_bwd_gather<M>(g, x, go, out, saved, gx, st); rc != kNotApplicable) return rc;
   if (int rc = launch_bwd_gather_banded<M>(g, x, go, out, saved, gx, st); rc != kNotApplicable) return rc;
-  g.Cc = kLdsBudgetBwd / (g.P * 4);
-  if (g.Cc < 1) g.Cc = 1;
-  if (g.Cc > g.C) g.Cc = g.C;
-  // enough channel blocks to put >= 256 workgroups on the chip when the batch is small
-  int want = (256 + g.B - 1) / (g.B > 0 ? g.B : 1);
-  int nblk = (g.C + g.Cc - 1) / g.Cc;
-  if (nblk < want) {
-    nblk = want < g.C ? want : g.C;
-    g.Cc = (g.C + nblk - 1) / nblk;
-    if (g.Cc < 1) g.Cc = 1;
-  }
-  g.Cwg = g.Cc;
-  g.Ow = g.O < 1024 ? g.O : 1024;
-  g.Tc = 1024 / g.Ow;
-  if (g.Tc > g.Cc) g.Tc = g.Cc;
-  int T = ((g.Ow * g.Tc + 63) / 64) * 64;
-  size_t lds = ((size_t)((g.Cc * g.P + 3) & ~3) + (size_t)g.Cc * g.P) * 4;
-  if (lds > (size_t)kLdsMax)
-    return fail(NFP_E_UNSUPPORTED, "backward: feature map %dx%d needs %zu B of LDS for one channel (x + grad slabs), "
-                "limit %d", g.H, g.W, lds, kLdsMax);
-  dim3 grid(g.B, (g.C + g.Cwg - 1) / g.Cwg);
-  snprintf(g_variant, sizeof(g_variant), "bwd_generic");
-  return launch("bwd_generic", bwd_generic<M>, grid, dim3(T), lds, st, g, x, go, out, saved, gx);
+  // last resort (nfp_direct.h): no LDS tables, any map size, still one writer per element in a fixed order
+  snprintf(g_variant, sizeof(g_variant), "bwd_direct");
+  return launch("bwd_direct", bwd_direct<M>, dim3((unsigned)((g.P + 255) / 256), (g.C + kDirectCB - 1) / kDirectCB, g.B),
+                dim3(256), 0, st, g, x, go, out, saved, gx);
 }
 
 // ---- fast-path launches (nfp_fast.h) ----------------------------------------------------------

@@ -407,7 +407,7 @@ template <int M> struct Pivot { static constexpr bool v = false; };
 template <> struct Pivot<NFP_PEARSON> { static constexpr bool v = true; };
 
 // ---- Attention   nfp.py:195-205: the dot products go through DotProduct's kernels; the softmax over
-// the N neighbours and its Jacobian are separate tiny kernels (nfp_generic.h).
+// the N neighbours and its Jacobian are separate tiny kernels (nfp_direct.h).
 template <>
 struct Meas<NFP_ATTENTION> : Meas<NFP_DOT> {};
 

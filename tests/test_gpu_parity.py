@@ -65,8 +65,8 @@ def _supported(c):
 def variant(request, monkeypatch):
     """'auto' = the dispatcher's choice (hot-path kernels where they apply); 'whole' = the same with the row-banded
     forward switched off (fwd_fast: one workgroup per image, the fused-pooling kernel's base); 'generic' forces the
-    any-geometry kernels of nfp_gather.h (fwd_pairs / bwd_gather); 'atomic' forces their fallbacks for maps
-    too large for those kernels' LDS tables (chunked scalar forward, LDS-atomic backward) — every
+    any-geometry kernels of nfp_gather.h (fwd_pairs / bwd_gather); 'atomic' (the switches' historical name) forces
+    the table-free kernels of last resort (nfp_direct.h) that serve maps too large for those kernels' LDS tables — every
     implementation is held to the same bar on every case."""
     nfp_switch(monkeypatch, "NFP_FORCE_GENERIC", "0" if request.param in ("auto", "whole") else "1")
     nfp_switch(monkeypatch, "NFP_FWD_BAND", "0" if request.param == "whole" else "1")
@@ -573,16 +573,16 @@ def test_gather_backward_geometry_sweep(B, C, H, W, R, pad, stride, dil, mode, m
     # the banded kernel (maps too large for whole-image tables), forced here onto 3 bands of rows
     nfp_switch(monkeypatch, "NFP_BWD_BANDS", "3")
     gxb, = torch.autograd.grad(out, x, go, retain_graph=True)
-    assert _abi.load().nfp_last_variant().decode() in ("bwd_gather_banded", "bwd_generic")
+    assert _abi.load().nfp_last_variant().decode() in ("bwd_gather_banded", "bwd_direct")
     assert rel_err(gxb.cpu().numpy(), gref.cpu().numpy()) <= 2 * TOL
     nfp_switch(monkeypatch, "NFP_BWD_BANDS", None)
     nfp_switch(monkeypatch, "NFP_BWD_ATOMIC", "1")
     nfp_switch(monkeypatch, "NFP_FWD_SCALAR", "1")
     gx3, = torch.autograd.grad(out, x, go)
-    assert _abi.load().nfp_last_variant().decode() == "bwd_generic"
+    assert _abi.load().nfp_last_variant().decode() == "bwd_direct"
     assert rel_err(gx3.cpu().numpy(), gref.cpu().numpy()) <= 2 * TOL
     out3 = m(x)
-    assert _abi.load().nfp_last_variant().decode() == "fwd_generic"
+    assert _abi.load().nfp_last_variant().decode() == "fwd_direct"
     assert rel_err(out3.detach().cpu().numpy(), ref.detach().cpu().numpy()) <= TOL
 
 
@@ -844,35 +844,37 @@ def test_attention_bf16_and_batch_strided_views(dev, oracle_lib):
     assert torch.equal(o1, o2) and torch.equal(g1, g2) and g1.is_contiguous()
 
 
-def test_forward_refuses_when_backward_is_not_served(dev):
-    """Forward and backward envelopes differ for a few shapes; a call that will need a gradient must fail in forward(),
-    not inside loss.backward() — and run fine under no_grad."""
+def test_forward_and_backward_envelopes_agree(dev):
+    """Round 1's forward served maps its backward refused (found out inside loss.backward()).  Now every descriptor
+    the forward serves, the backward serves too (nfp_direct.h is the table-free last resort of both); and should a
+    backward ever be unserved, functional.nfp refuses in forward() when a gradient is needed (`no_bwd` in the plan)."""
     import ctypes
     from neighbour_feature_pooling_amd import NFPPooling, _abi, functional
     L = _abi.load()
-    found = None
-    for (C, H, W, R) in [(4, 400, 400, 1), (4, 300, 300, 2), (4, 200, 200, 3), (8, 160, 160, 1)]:
+    buf = ctypes.create_string_buffer(1024)
+    for (C, H, W, R, meas) in [(4, 400, 400, 1, "cosine"), (4, 300, 300, 2, "cosine"), (4, 200, 200, 3, "norm"),
+                               (8, 160, 160, 1, "cosine"), (8, 144, 144, 2, "pearson"), (3, 2, 5000, 1, "dot")]:
         x = torch.zeros(1, C, H, W, device=dev)
-        cfg = NFPPooling(C, R=R, measure="cosine", padding=R).config
-        try:
-            d = functional.make_desc(x, cfg)
-        except _abi.NfpError:
-            continue
-        buf = ctypes.create_string_buffer(1024)
-        if L.nfp_plan(ctypes.byref(d), 0, buf, 1024) == 0 and L.nfp_plan(ctypes.byref(d), 1, buf, 1024) != 0:
-            found = (C, H, W, R)
-            break
-    if found is None:
-        pytest.skip("every probed shape is served by both passes")
-    C, H, W, R = found
-    m = NFPPooling(C, R=R, measure="cosine", padding=R)
-    x = torch.randn(1, C, H, W, device=dev, requires_grad=True)
-    n0 = _launches()
-    with pytest.raises(_abi.NfpUnsupported, match="backward is not"):
-        m(x)
-    assert _launches() == n0
-    with torch.no_grad():
-        assert m(x).shape == (1, (2 * R + 1) ** 2 - 1, H, W)
+        d = functional.make_desc(x, NFPPooling(C, R=R, measure=meas, padding=R).config)
+        assert L.nfp_plan(ctypes.byref(d), 0, buf, 1024) == 0, L.nfp_last_error()
+        assert L.nfp_plan(ctypes.byref(d), 1, buf, 1024) == 0, L.nfp_last_error()
+    # the refusal path itself, with a plan whose backward is marked unserved
+    m = NFPPooling(8, R=1, measure="cosine", padding=1)
+    x = torch.randn(2, 8, 6, 6, device=dev, requires_grad=True)
+    m(x)                                                        # builds the plan
+    key = next(k for k in functional._PLANS if k[0] == (2, 8, 6, 6))
+    d_, shape_, ns_, _ = functional._PLANS[key]
+    functional._PLANS[key] = (d_, shape_, ns_, "test: backward unserved")
+    try:
+        n0 = _launches()
+        with pytest.raises(_abi.NfpUnsupported, match="backward is not"):
+            m(x)
+        assert _launches() == n0
+        with torch.no_grad():
+            assert m(x).shape == (2, 8, 6, 6)
+        assert m(x.detach()).shape == (2, 8, 6, 6)
+    finally:
+        del functional._PLANS[key]
 
 
 # ---- configs[3] / configs[4] end to end: DDP over an RCCL process group (world size 1 on this box) ---------------
@@ -934,3 +936,46 @@ def test_config5_vit_tiny_nfp_bf16_ddp_step_rccl_bs256(dev, rccl_group):
     _ddp_step(net, x, y, dev)
     bv = _abi.load().nfp_last_variant().decode()
     assert bv.startswith("bwd_fast<R2,l2,bf16,nhwc"), bv
+
+
+# ---- large maps: the MultiStage feature maps of texture_pooling.py:211-268 and maps beyond every LDS table ---------
+
+@pytest.mark.parametrize("name", ["ms_cos_112x112x16", "ms_cos_56x56x24", "ms_cos_28x28x40", "ms_cos_14x14x112",
+                                  "ms_cos_7x7x960", "geo_cos_224x224", "geo_l2_k5_160x160"])
+def test_multistage_and_large_maps_match_reference_golden(name, dev):
+    """MobileNetV3_MultiStageNFP feeds NFP 112x112x16 ... 7x7x960 maps; 224x224 is the reference's default
+    input_size; 160x160 with k = 5 is beyond the banded backward's tables.  Default dispatch, forward AND backward
+    served, bitwise reproducible, against the real reference's outputs."""
+    from neighbour_feature_pooling_amd import _abi
+    c = K.BY_NAME[name]
+    g = load_golden(name)
+    out, gx, _ = run_hip(c, dev)
+    fv_bv = _abi.load().nfp_last_variant().decode()
+    assert_matches_golden(out, gx, g, TOL, 2 * TOL)
+    out2, gx2, _ = run_hip(c, dev)
+    assert np.array_equal(out, out2) and np.array_equal(gx, gx2), fv_bv
+
+
+def test_direct_kernels_serve_what_no_table_kernel_can(dev):
+    """A map wider than any LDS row window / pair table: the kernels of last resort (nfp_direct.h), against the float64
+    formulation; and the forward/backward envelopes agree (nothing is refused in backward that forward served)."""
+    from neighbour_feature_pooling_amd import NFPPooling, _abi
+    from neighbour_feature_pooling_amd._host import nfp_host
+    for (B, C, H, W, ctor) in [(1, 3, 6, 3000, dict(R=2, measure="cosine", padding=2)),
+                               (1, 5, 300, 280, dict(R=1, measure="pearson", padding=1, padding_mode="circular")),
+                               (2, 4, 150, 170, dict(R=3, measure="norm", p=2, padding=3, stride=2))]:
+        m = NFPPooling(C, **ctor)
+        gen = torch.Generator().manual_seed(H + W)
+        x = (torch.rand(B, C, H, W, generator=gen) + 0.25).to(dev).requires_grad_(True)
+        out = m(x)
+        fv = _abi.load().nfp_last_variant().decode()
+        go = torch.randn(out.shape, generator=gen).to(dev)
+        gx, = torch.autograd.grad(out, x, go, retain_graph=True)
+        bv = _abi.load().nfp_last_variant().decode()
+        gx2, = torch.autograd.grad(out, x, go)
+        assert torch.equal(gx, gx2), (fv, bv)
+        x64 = x.detach().double().requires_grad_(True)
+        ref = nfp_host(x64, m.config)
+        gref, = torch.autograd.grad(ref, x64, go.double())
+        assert rel_err(out.detach().cpu().numpy(), ref.detach().cpu().numpy()) <= 1e-4, (fv, bv)
+        assert rel_err(gx.cpu().numpy(), gref.cpu().numpy()) <= 2e-4, (fv, bv)
