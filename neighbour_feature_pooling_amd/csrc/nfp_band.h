@@ -31,10 +31,14 @@ struct FoffQ {
   static constexpr int v = ((Win<R>::NF + 7) & ~7) / 8;  // 16-byte pieces of a pixel's foff row (ws_layout: FR)
 };
 
-template <int R, int M, bool BF, bool NHWC>
+// POOL = the fused tail of models/NFP_Pooling.py:27-31 (one band = the whole image): besides the neighbour maps the
+// same pass emits  gap[b,c] = mean over pixels of x[b,c]  (AdaptiveAvgPool2d(1), NFP_Pooling.py:27) and
+// nfpm[b,n] = mean over pixels of out[b,n]  (adaptive_avg_pool2d of the NFP maps, NFP_Pooling.py:31), both float32,
+// summed in a fixed order, for either layout and storage type (the sums are taken from the float32 LDS slab).
+template <int R, int M, bool BF, bool NHWC, bool POOL = false>
 __global__ void __launch_bounds__(kBandT) fwd_band(const KP g, const void* __restrict__ x, void* __restrict__ out,
                                                    float* __restrict__ saved, const unsigned char* __restrict__ ws,
-                                                   int rb) {
+                                                   int rb, float* __restrict__ gap, float* __restrict__ nfpm) {
   constexpr int N = Win<R>::N, NF = Win<R>::NF;
   constexpr int ES = BF ? 2 : 4;
   extern __shared__ __attribute__((aligned(16))) float4 lds4[];
@@ -141,6 +145,33 @@ __global__ void __launch_bounds__(kBandT) fwd_band(const KP g, const void* __res
     commit(ncq);
     __syncthreads();
     if (c0 == 0) NFP_STAMP(2);
+    if constexpr (POOL) {
+      // channel means of this chunk: four adjacent lanes per channel quad, lane `part` sums pixels part, part + 4, ...;
+      // joined by a fixed xor tree
+      for (int i0 = 0; i0 < ncq * 4; i0 += T) {
+        const int i = i0 + t, cq = min(i >> 2, ncq - 1), part = i & 3;
+        float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int pp = part; pp < P; pp += 4) {
+          const float4 v = slab[cq * Ppb + swz(pp) - base];
+          s4.x += v.x;
+          s4.y += v.y;
+          s4.z += v.z;
+          s4.w += v.w;
+        }
+        auto join = [](float v) {
+          v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false));
+          v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, false));
+          return v;
+        };
+        s4.x = join(s4.x);
+        s4.y = join(s4.y);
+        s4.z = join(s4.z);
+        s4.w = join(s4.w);
+        if (i < ncq * 4 && part == 0)
+          *(float4*)(gap + (long long)b * g.C + c0 + 4 * cq) =
+              make_float4(s4.x * g.invP, s4.y * g.invP, s4.z * g.invP, s4.w * g.invP);
+      }
+    }
     if (active) {
       for (int cq = gl; cq < ncq; cq += G) {
         const float4* row = slab + cq * Ppb + sp;
@@ -220,9 +251,22 @@ __global__ void __launch_bounds__(kBandT) fwd_band(const KP g, const void* __res
           v = g.similarity ? -dd : dd;
         }
         stx(ob, n * P + p, v, BF ? NFP_BF16 : NFP_F32);
+        if constexpr (POOL) Tt[NV + n * Ps + lp] = v;  // vm[n][p], behind the half-stencil table
       }
     }
     if (M == NFP_COSINE && saved != nullptr && gl == 0 && p < po) saved[(long long)b * P + p] = __builtin_amdgcn_sqrtf(n2p);
+  }
+  if constexpr (POOL) {
+    __syncthreads();
+    // wave w reduces map n = w, w + nwaves, ...: lane-strided partial sums, then a fixed shuffle tree
+    const float* vm = Tt + NV;
+    const int lane = t & 63, wv = t >> 6, nw = T >> 6;
+    for (int n = wv; n < N; n += nw) {
+      float sacc = 0.f;
+      for (int i = lane; i < P; i += 64) sacc += vm[n * Ps + i];
+      for (int m = 32; m >= 1; m >>= 1) sacc += __shfl_xor(sacc, m);
+      if (lane == 0) nfpm[(long long)b * N + n] = sacc * g.invP;
+    }
   }
   NFP_STAMP(5);
 }

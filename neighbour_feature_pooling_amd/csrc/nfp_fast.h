@@ -473,9 +473,10 @@ __global__ void __launch_bounds__(MAXT) fwd_fast(const KP g, const void* __restr
 // Row tiles are processed a few at a time (Wd of all of them does not fit next to Xt at config 5's shape: g.Tc).
 __device__ __forceinline__ int odd_up(int v) { return v | 1; }
 
+// gg: grad of the pooled channel means of this image (fused pooling tail) or null: every grad_x[c][p] also gets gg[c]/P.
 template <int R, bool NHWC>
 __device__ __forceinline__ void bwd_gemm_phase(const KP& g, const float* Wt, uint4* scratch, const uint16_t* xb,
-                                               uint16_t* gxb, int cb0, int cb1, int t, int T) {
+                                               uint16_t* gxb, int cb0, int cb1, int t, int T, const float* gg = nullptr) {
   constexpr int K = Win<R>::K, K2 = Win<R>::K2;
   const int P = g.P, C = g.C, band = R * g.W + R, nt = (P + 31) >> 5;
   const int KW = (32 + 2 * band + 15 + 15) >> 4;            // k-steps that cover a row tile's window after aligning its start
@@ -584,14 +585,17 @@ __device__ __forceinline__ void bwd_gemm_phase(const KP& g, const float* Wt, uin
       const uint4* Wh = Wd + (long long)(ri * 2 * 32 + r) * wq + h;
       const uint4* Wl = Wh + 32 * wq;
       const uint4* Xr = Xt + (long long)(32 * ct + r) * xq + (ts >> 3) + h;
-      f32x16 acc;
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[e] = 0.f;
       // Orientation: the accumulator holds 4 CONSECUTIVE rows per register group, so the output index that is
       // contiguous in memory goes on the rows and leaves as one 8-byte store per group: channels for
       // channels-last (A = Xt), pixels for NCHW (A = Wd; needs P % 4 == 0 for the alignment, otherwise pixels
       // stay on the lanes and leave as 2-byte stores).
       const bool rows_are_channels = NHWC || (P & 3) != 0;
+      f32x16 acc;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {  // element e of lane (r, h) is D[row (e & 3) + 8 (e >> 2) + 4 h][column r]
+        const int ch = 32 * ct + (rows_are_channels ? (e & 3) + 8 * (e >> 2) + 4 * h : r);
+        acc[e] = gg != nullptr ? gg[cb0 + ch] * g.invP : 0.f;
+      }
       for (int s = 0; s < ks; ++s) {
         const bf16x8 wh = __builtin_bit_cast(bf16x8, Wh[2 * s]), wl = __builtin_bit_cast(bf16x8, Wl[2 * s]);
         const bf16x8 xv = __builtin_bit_cast(bf16x8, Xr[2 * s]);
@@ -652,8 +656,7 @@ __global__ void __launch_bounds__(GEMM ? 1024 : kBwdThreads) bwd_fast(const KP g
                                                         const float* __restrict__ ggap,
                                                         const float* __restrict__ gnfpm,
                                                         const unsigned char* __restrict__ ws) {
-  static_assert(!POOL || (!BF && !NHWC), "fused pooling tail: NCHW float32 only");
-  static_assert(!GEMM || (BF && !POOL), "matrix-core phase B: bf16 storage only");
+  static_assert(!GEMM || BF, "matrix-core phase B: bf16 storage only");
   constexpr int K2 = Win<R>::K2, N = Win<R>::N;
   // the diagonal is folded by a phase of its own when the weights are consumed as a table (matrix cores) or the
   // window is large; for k = 3 every compute thread folds its own pixel's nine terms while it loads its weights
@@ -884,7 +887,8 @@ __global__ void __launch_bounds__(GEMM ? 1024 : kBwdThreads) bwd_fast(const KP g
   if constexpr (GEMM) {
     // (the pair values behind the tables are dead: their LDS becomes the GEMM's operand images)
     bwd_gemm_phase<R, NHWC>(g, Wt, (uint4*)pv4, (const uint16_t*)x + (long long)b * g.sB,
-                            (uint16_t*)gx + (long long)b * g.gB, cb0, cb1, t, T);
+                            (uint16_t*)gx + (long long)b * g.gB, cb0, cb1, t, T,
+                            POOL ? ggap + (long long)b * g.C : nullptr);
     return;
   }
   float w[K2];

@@ -522,10 +522,12 @@ int launch_fwd_fast_t(KP g, const void* x, void* out, float* saved, hipStream_t 
 #ifndef NFP_BAND_WGS
 #define NFP_BAND_WGS 256
 #endif
-template <int R, int M, bool BF, bool NHWC>
-int launch_fwd_band_t(KP g, const void* x, void* out, float* saved, hipStream_t st) {
+template <int R, int M, bool BF, bool NHWC, bool POOL = false>
+int launch_fwd_band_t(KP g, const void* x, void* out, float* saved, hipStream_t st, float* gap = nullptr,
+                      float* nfpm = nullptr) {
   constexpr int NF = Win<R>::NF;
   int nb = std::min(g.H, (NFP_BAND_WGS + g.B - 1) / g.B);   // bands per image so that >= NFP_BAND_WGS workgroups exist
+  if (POOL) nb = 1;   // the pooled outputs are sums over the whole image: one workgroup per image, nothing to combine
   const int rb = (g.H + nb - 1) / nb;
   nb = (g.H + rb - 1) / rb;
   const int psm = std::min(g.P, (rb + g.R) * g.W);          // most pixels a band stages
@@ -537,12 +539,13 @@ int launch_fwd_band_t(KP g, const void* x, void* out, float* saved, hipStream_t 
   const int total = g.C / 4, nch = (total + ncq - 1) / ncq;
   g.Cc = 4 * ((total + nch - 1) / nch);
   const size_t slab = (size_t)(g.Cc / 4) * ppb * 16;
-  const size_t red = (size_t)(kBandT + psm) * (NF + 1) * 4;
+  const size_t red = (size_t)(kBandT + psm) * (NF + 1) * 4 + (POOL ? (size_t)Win<R>::N * psm * 4 : 0);
   const size_t lds = std::max(slab, red);
   if (lds > (size_t)kLdsMax) return kNotApplicable;
-  snprintf(g_variant, sizeof(g_variant), "fwd_band<R%d,%s,%s,%s>x%d", R, M == NFP_COSINE ? "cos" : "l2", BF ? "bf16" : "f32",
-           NHWC ? "nhwc" : "nchw", nb);
-  return launch("fwd_band", fwd_band<R, M, BF, NHWC>, dim3(g.B, nb), dim3(kBandT), lds, st, g, x, out, saved, g.ws, rb);
+  snprintf(g_variant, sizeof(g_variant), "fwd_band<R%d,%s,%s,%s%s>x%d", R, M == NFP_COSINE ? "cos" : "l2",
+           BF ? "bf16" : "f32", NHWC ? "nhwc" : "nchw", POOL ? ",pool" : "", nb);
+  return launch("fwd_band", fwd_band<R, M, BF, NHWC, POOL>, dim3(g.B, nb), dim3(kBandT), lds, st, g, x, out, saved, g.ws,
+                rb, gap, nfpm);
 }
 
 template <int R, int M>
@@ -628,9 +631,9 @@ int launch_fwd_gram(const KP& g, const void* x, void* out, float* saved, hipStre
 }
 
 // Phase B of the backward on the matrix cores (nfp_fast.h::bwd_gemm_phase): bf16 storage, C a multiple of 32.
-template <int R, int M, bool NHWC>
+template <int R, int M, bool NHWC, bool POOL = false>
 int launch_bwd_gemm_t(KP g, const void* x, const void* go, const void* out, const float* saved, void* gx,
-                      hipStream_t st) {
+                      hipStream_t st, const float* ggap = nullptr, const float* gnfpm = nullptr) {
   constexpr int N = Win<R>::N, K2 = Win<R>::K2;
   if (!mfma_enabled() || g.dtype != NFP_BF16 || (g.C & 31)) return kNotApplicable;
   if (NHWC && (((uintptr_t)x & 15) || ((g.sB * 2) & 15))) return kNotApplicable;  // 16-byte staging loads
@@ -663,10 +666,10 @@ int launch_bwd_gemm_t(KP g, const void* x, const void* go, const void* out, cons
   const size_t lds = fixed + std::max(bwd_pair_bytes(g, M, N), images);
   g.early = 0;
   if (lds > (size_t)kLdsMax) return kNotApplicable;
-  snprintf(g_variant, sizeof(g_variant), "bwd_fast<R%d,%s,bf16,%s,mfma>", R, M == NFP_COSINE ? "cos" : "l2",
-           NHWC ? "nhwc" : "nchw");
-  return launch("bwd_fast_mfma", bwd_fast<R, M, true, NHWC, false, true>, dim3(g.B, S), dim3(T), lds, st, g, x, go, out,
-                saved, gx, (const float*)nullptr, (const float*)nullptr, g.ws);
+  snprintf(g_variant, sizeof(g_variant), "bwd_fast<R%d,%s,bf16,%s,mfma%s>", R, M == NFP_COSINE ? "cos" : "l2",
+           NHWC ? "nhwc" : "nchw", POOL ? ",pool" : "");
+  return launch("bwd_fast_mfma", bwd_fast<R, M, true, NHWC, POOL, true>, dim3(g.B, S), dim3(T), lds, st, g, x, go, out,
+                saved, gx, ggap, gnfpm, g.ws);
 }
 
 template <int R, int M>
@@ -859,6 +862,29 @@ int backward_impl(const nfp_desc* d, const void* x, const void* grad_out, const 
   }
 }
 
+template <int R, int M>
+int pool_forward_rm(const KP& g, const void* x, void* out_map, float* saved, hipStream_t st, float* gap, float* nfpm) {
+  const bool bf = g.dtype == NFP_BF16, nhwc = !g.contig;
+  if (bf) return nhwc ? launch_fwd_band_t<R, M, true, true, true>(g, x, out_map, saved, st, gap, nfpm)
+                      : launch_fwd_band_t<R, M, true, false, true>(g, x, out_map, saved, st, gap, nfpm);
+  return nhwc ? launch_fwd_band_t<R, M, false, true, true>(g, x, out_map, saved, st, gap, nfpm)
+              : launch_fwd_band_t<R, M, false, false, true>(g, x, out_map, saved, st, gap, nfpm);
+}
+template <int R, int M>
+int pool_backward_rm(const KP& g, const void* x, const void* out_map, const float* saved, void* gx, hipStream_t st,
+                     const float* ggap, const float* gnfpm) {
+  const bool bf = g.dtype == NFP_BF16, nhwc = !g.contig;
+  if (bf) {  // phase B on the matrix cores where it applies, as in nfp_backward
+    const int rc = nhwc ? launch_bwd_gemm_t<R, M, true, true>(g, x, nullptr, out_map, saved, gx, st, ggap, gnfpm)
+                        : launch_bwd_gemm_t<R, M, false, true>(g, x, nullptr, out_map, saved, gx, st, ggap, gnfpm);
+    if (rc != kNotApplicable) return rc;
+    return nhwc ? launch_bwd_fast_t<R, M, true, true, true>(g, x, nullptr, out_map, saved, gx, st, ggap, gnfpm)
+                : launch_bwd_fast_t<R, M, true, false, true>(g, x, nullptr, out_map, saved, gx, st, ggap, gnfpm);
+  }
+  return nhwc ? launch_bwd_fast_t<R, M, false, true, true>(g, x, nullptr, out_map, saved, gx, st, ggap, gnfpm)
+              : launch_bwd_fast_t<R, M, false, false, true>(g, x, nullptr, out_map, saved, gx, st, ggap, gnfpm);
+}
+
 }  // namespace
 
 extern "C" {
@@ -953,30 +979,31 @@ int nfp_plan(const nfp_desc* d, int32_t backward, char* buf, int32_t buflen) {
 int nfp_pool_supported(const nfp_desc* d) {
   KP g;
   if (make_kp(d, &g)) return 0;
-  // hot-path geometry, NCHW float32 (x pointer alignment does not matter for NCHW), tables must fit LDS
-  if (!(g.dtype == NFP_F32 && g.contig && fast_ok(g, nullptr, nullptr))) return 0;
-  if (g.ws == nullptr) return 0;  // the backward reads its index maps from the workspace
+  // hot-path geometry (either layout, float32 or bf16) with its workspace tables; the backward's tables must fit LDS.
+  // Pointer alignment is the caller's: channels-last maps need 16-byte aligned images (as nfp_forward's hot path).
+  if (g.ws == nullptr || !fast_ok(g, nullptr, nullptr)) return 0;
   const int K2 = g.k * g.k;
   const size_t bwd_tables = bwd_fixed_bytes(g, K2) + bwd_pair_bytes(g, g.measure, g.N);
   return bwd_tables + 64 <= (size_t)kLdsMax ? 1 : 0;  // the x slab shares the pair values' region (dead by then)
 }
+
 
 int nfp_pool_forward(const nfp_desc* d, const void* x, float* gap, float* nfpm, void* out_map, float* saved,
                      void* hip_stream) {
   KP g;
   if (int rc = make_kp(d, &g)) return rc;
   if (!x || !gap || !nfpm || !out_map) return fail(NFP_E_INVALID, "null tensor pointer");
-  if (!nfp_pool_supported(d))
-    return fail(NFP_E_UNSUPPORTED, "fused pooling tail: hot-path geometry, NCHW float32, descriptor with a workspace only");
+  if (!nfp_pool_supported(d) || !fast_ok(g, x, x))
+    return fail(NFP_E_UNSUPPORTED, "fused pooling tail: hot-path geometry, descriptor with a workspace only");
   if (g.B == 0) return NFP_OK;
   hipStream_t st = (hipStream_t)hip_stream;
   int rc;
   if (g.measure == NFP_COSINE)
-    rc = g.R == 1 ? launch_fwd_fast_t<1, NFP_COSINE, false, false, true>(g, x, out_map, saved, st, gap, nfpm)
-                  : launch_fwd_fast_t<2, NFP_COSINE, false, false, true>(g, x, out_map, saved, st, gap, nfpm);
+    rc = g.R == 1 ? pool_forward_rm<1, NFP_COSINE>(g, x, out_map, saved, st, gap, nfpm)
+                  : pool_forward_rm<2, NFP_COSINE>(g, x, out_map, saved, st, gap, nfpm);
   else
-    rc = g.R == 1 ? launch_fwd_fast_t<1, NFP_NORM, false, false, true>(g, x, out_map, saved, st, gap, nfpm)
-                  : launch_fwd_fast_t<2, NFP_NORM, false, false, true>(g, x, out_map, saved, st, gap, nfpm);
+    rc = g.R == 1 ? pool_forward_rm<1, NFP_NORM>(g, x, out_map, saved, st, gap, nfpm)
+                  : pool_forward_rm<2, NFP_NORM>(g, x, out_map, saved, st, gap, nfpm);
   return finish(rc, "nfp_pool_forward");
 }
 
@@ -985,18 +1012,18 @@ int nfp_pool_backward(const nfp_desc* d, const void* x, const float* grad_gap, c
   KP g;
   if (int rc = make_kp(d, &g)) return rc;
   if (!x || !grad_gap || !grad_nfpm || !out_map || !grad_x) return fail(NFP_E_INVALID, "null tensor pointer");
-  if (!nfp_pool_supported(d))
-    return fail(NFP_E_UNSUPPORTED, "fused pooling tail: hot-path geometry, NCHW float32, descriptor with a workspace only");
+  if (!nfp_pool_supported(d) || !fast_ok(g, x, grad_x))
+    return fail(NFP_E_UNSUPPORTED, "fused pooling tail: hot-path geometry, descriptor with a workspace only");
   if (stats_of(g.measure) > 0 && !saved) return fail(NFP_E_INVALID, "missing saved state");
   if (g.B == 0) return NFP_OK;
   hipStream_t st = (hipStream_t)hip_stream;
   int rc;
   if (g.measure == NFP_COSINE)
-    rc = g.R == 1 ? launch_bwd_fast_t<1, NFP_COSINE, false, false, true>(g, x, nullptr, out_map, saved, grad_x, st, grad_gap, grad_nfpm)
-                  : launch_bwd_fast_t<2, NFP_COSINE, false, false, true>(g, x, nullptr, out_map, saved, grad_x, st, grad_gap, grad_nfpm);
+    rc = g.R == 1 ? pool_backward_rm<1, NFP_COSINE>(g, x, out_map, saved, grad_x, st, grad_gap, grad_nfpm)
+                  : pool_backward_rm<2, NFP_COSINE>(g, x, out_map, saved, grad_x, st, grad_gap, grad_nfpm);
   else
-    rc = g.R == 1 ? launch_bwd_fast_t<1, NFP_NORM, false, false, true>(g, x, nullptr, out_map, saved, grad_x, st, grad_gap, grad_nfpm)
-                  : launch_bwd_fast_t<2, NFP_NORM, false, false, true>(g, x, nullptr, out_map, saved, grad_x, st, grad_gap, grad_nfpm);
+    rc = g.R == 1 ? pool_backward_rm<1, NFP_NORM>(g, x, out_map, saved, grad_x, st, grad_gap, grad_nfpm)
+                  : pool_backward_rm<2, NFP_NORM>(g, x, out_map, saved, grad_x, st, grad_gap, grad_nfpm);
   return finish(rc, "nfp_pool_backward");
 }
 

@@ -239,8 +239,8 @@ class _NfpPoolHip(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, cfg):
         L = _abi.load()
-        x = x.contiguous()
-        d, (B, N, Ho, Wo), ns, _ = _plan(x, "nchw", cfg)
+        x, layout = _dense(x)
+        d, (B, N, Ho, Wo), ns, _ = _plan(x, layout, cfg)
         with _on_device(x.device):
             gap = torch.empty(B, x.shape[1], dtype=torch.float32, device=x.device)
             nfpm = torch.empty(B, N, dtype=torch.float32, device=x.device)
@@ -250,6 +250,7 @@ class _NfpPoolHip(torch.autograd.Function):
             _abi.check(L.nfp_pool_forward(ctypes.byref(d), x.data_ptr(), gap.data_ptr(), nfpm.data_ptr(),
                                           out_map.data_ptr(), saved.data_ptr() if ns > 0 else None, stream))
         ctx.desc = d
+        ctx.layout = layout
         ctx.save_for_backward(x, out_map, saved)
         return gap, nfpm
 
@@ -261,7 +262,8 @@ class _NfpPoolHip(torch.autograd.Function):
         g_gap = g_gap.contiguous().float()
         g_nfpm = g_nfpm.contiguous().float()
         with _on_device(x.device):
-            gx = torch.empty_like(x)
+            gx = torch.empty(x.shape, dtype=x.dtype, device=x.device,
+                             memory_format=torch.channels_last if ctx.layout == "nhwc" else torch.contiguous_format)
             stream = _raw_stream(x.device)
             _abi.check(L.nfp_pool_backward(ctypes.byref(ctx.desc), x.data_ptr(), g_gap.data_ptr(), g_nfpm.data_ptr(),
                                            out_map.data_ptr(), saved.data_ptr() if saved.numel() else None,
@@ -270,13 +272,19 @@ class _NfpPoolHip(torch.autograd.Function):
 
 
 def nfp_pool_fused_ok(x, cfg):
-    """True when the fused GAP + pooled-NFP kernels can serve this call (hot-path geometry, NCHW f32)."""
-    if not (x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and x.is_contiguous()):
+    """True when the fused GAP + pooled-NFP kernels can serve this call: hot-path geometry (stride 1, pad = R, cosine
+    or L2), float32 or bfloat16, images dense in NCHW or channels-last order."""
+    if not (x.is_cuda and x.dim() == 4 and x.dtype in _DTYPES):
         return False
-    key = ("pool", tuple(x.shape), cfg, x.device.index)
+    layout = _inner_layout(x)
+    if layout is None or (x.shape[0] > 1 and x.stride(0) < x.shape[1] * x.shape[2] * x.shape[3]):
+        return False
+    if layout == "nhwc" and (x.data_ptr() % 16 or (x.stride(0) * x.element_size()) % 16):
+        return False          # (the channels-last kernels load 16 bytes per lane)
+    key = ("pool", tuple(x.shape), x.stride(0), layout, x.dtype, cfg, x.device.index)
     ok = _plans_get(key)
     if ok is None:
-        ok = bool(_abi.load().nfp_pool_supported(ctypes.byref(_plan(x, "nchw", cfg)[0])))
+        ok = bool(_abi.load().nfp_pool_supported(ctypes.byref(_plan(x, layout, cfg)[0])))
         _plans_put(key, ok)
     return ok
 
