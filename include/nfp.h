@@ -162,7 +162,7 @@ const char* nfp_last_variant(void);
 void nfp_time_next_launch(void* start_event, void* stop_event);
 
 /* Test hook: re-read the NFP_* A/B switches (NFP_FORCE_GENERIC, NFP_FWD_SCALAR,
- * NFP_BWD_ATOMIC, NFP_BWD_BANDS, NFP_MFMA, NFP_FWD_BAND) from the environment.  They are
+ * NFP_BWD_ATOMIC, NFP_BWD_BANDS, NFP_MFMA) from the environment.  They are
  * otherwise read once, when the library is loaded. */
 void nfp_reload_env(void);
 

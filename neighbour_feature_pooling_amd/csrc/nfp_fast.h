@@ -34,22 +34,14 @@ namespace nfp {
 #ifndef NFP_RB
 #define NFP_RB 3
 #endif
-#ifndef NFP_FWD_THREADS
-#define NFP_FWD_THREADS 512
-#endif
 #ifndef NFP_BWD_THREADS
 #define NFP_BWD_THREADS 512
-#endif
-#ifndef NFP_UNROLL_F
-#define NFP_UNROLL_F 1
 #endif
 #ifndef NFP_UNROLL_B
 #define NFP_UNROLL_B 1
 #endif
 constexpr int kRB = NFP_RB;  // NCHW staging: 4x4 blocks per thread per chunk
-constexpr int kRT = 2;    // NCHW staging: tail (P % 4) pixel slots per thread per chunk
 constexpr int kRN = 4;    // channels-last staging: slots per thread per chunk
-constexpr int kFwdThreads = NFP_FWD_THREADS;  // every instruction costs (waves per SIMD) x 2 clk of CU issue time
 constexpr int kBwdThreads = NFP_BWD_THREADS;  // backward keeps (2R+1)^2 weights + offsets + staged x in registers
 
 // exact i / d for 0 <= i, quotient < 2048 (d >= 1): float multiply instead of the ~20-instruction
@@ -112,75 +104,9 @@ __device__ __forceinline__ void store_1(Rsrc r, int e, int srow, float v) {
 template <bool NHWC>
 struct Staged;
 template <>
-struct Staged<false> {
-  float4 blk[kRB][4];  // [round][channel j] = 4 consecutive pixels of channel 4cq+j
-  float4 tl[kRT];      // 4 channels of one tail pixel
-};
-template <>
 struct Staged<true> {
   float4 v[kRN];
 };
-
-// NCHW issue order: tail pixels first, then block round 0, then block round 1 — data returns in
-// issue order, so the slab can be committed and consumed round by round while later loads fly.
-template <bool BF>
-__device__ __forceinline__ void stage_load(Staged<false>& s, Rsrc x, const KP& g, int c0, int ncq, int t, int T) {
-  // straight-line: no branch may wrap a load (hipcc would wait for the loads inside it before
-  // issuing the next ones).  P >= 4 is guaranteed by the dispatcher; with P % 4 == 0 the tail
-  // loads degenerate to clamped duplicates of the last pixel and nothing is stored from them.
-  const int P = g.P, NQ = P >> 2, PT = P & 3;
-  const int nblk = ncq * NQ, ntl = ncq * PT;
-  const float invq = g.invNQ, invt = g.invPT;
-#pragma unroll
-  for (int r = 0; r < kRT; ++r) {
-    const int i = max(min(t + r * T, ntl - 1), 0);
-    const int cq = fast_div(i, invt), pt = i - cq * max(PT, 1);
-    const int e = (c0 + 4 * cq) * P + min(4 * NQ + pt, P - 1);
-    s.tl[r].x = load_1<BF>(x, e, 0);
-    s.tl[r].y = load_1<BF>(x, e, P);
-    s.tl[r].z = load_1<BF>(x, e, 2 * P);
-    s.tl[r].w = load_1<BF>(x, e, 3 * P);
-  }
-#pragma unroll
-  for (int r = 0; r < kRB; ++r) {
-    const int i = min(t + r * T, nblk - 1);
-    const int cq = fast_div(i, invq), pq = i - cq * NQ;
-    const int e = (c0 + 4 * cq) * P + 4 * pq;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) s.blk[r][j] = load_px4<BF>(x, e, j * P);
-  }
-}
-// commit the tail slots and block round `r0..r1-1`
-template <bool BF>
-__device__ __forceinline__ void stage_store(const Staged<false>& s, float4* slab, const KP& g, int ncq, int t, int T,
-                                            bool tails, int r0, int r1) {
-  const int P = g.P, NQ = P >> 2, PT = P & 3, Pp = (P + 3) & ~3;
-  const int nblk = ncq * NQ, ntl = ncq * PT;
-  const float invq = g.invNQ, invt = g.invPT;
-  if (tails) {
-#pragma unroll
-    for (int r = 0; r < kRT; ++r) {
-      const int i = t + r * T;
-      if (i < ntl) {
-        const int cq = fast_div(i, invt), pt = i - cq * PT;
-        slab[cq * Pp + swz(4 * NQ + pt)] = s.tl[r];
-      }
-    }
-  }
-#pragma unroll
-  for (int r = 0; r < kRB; ++r) {
-    const int i = t + r * T;
-    if (r >= r0 && r < r1 && i < nblk) {
-      const int cq = fast_div(i, invq), pq = i - cq * NQ;
-      float4* d = slab + cq * Pp + 4 * pq;
-      const int rot = (pq >> 1) & 3;  // = swz() of the block's four pixels
-      d[rot] = make_float4(s.blk[r][0].x, s.blk[r][1].x, s.blk[r][2].x, s.blk[r][3].x);
-      d[(rot + 1) & 3] = make_float4(s.blk[r][0].y, s.blk[r][1].y, s.blk[r][2].y, s.blk[r][3].y);
-      d[(rot + 2) & 3] = make_float4(s.blk[r][0].z, s.blk[r][1].z, s.blk[r][2].z, s.blk[r][3].z);
-      d[(rot + 3) & 3] = make_float4(s.blk[r][0].w, s.blk[r][1].w, s.blk[r][2].w, s.blk[r][3].w);
-    }
-  }
-}
 
 // channels-last: slot (cq, p) is 4 contiguous channels; thread (p, gl) takes cq = gl, gl+G, ...
 template <bool BF>
@@ -238,227 +164,10 @@ __device__ __forceinline__ void stage_store_ovl(const StagedOvl& s, float4* slab
   }
 }
 
-template <bool BF, bool NHWC>
-__device__ __forceinline__ void stage_issue(Staged<NHWC>& s, Rsrc x, const KP& g, int c0, int ncq, int t, int T,
-                                            int p, int gl, bool active) {
-  if constexpr (NHWC)
-    stage_load<BF>(s, x, g, c0, ncq, p, gl, active);
-  else
-    stage_load<BF>(s, x, g, c0, ncq, t, T);
-}
-// Commit stage `part` of kParts (NCHW: part r = block round r, tails with part 0; channels-last has
-// a single effective part).  Returns the number of channel quads complete after it.
-template <bool BF, bool NHWC>
-__device__ __forceinline__ int stage_commit(const Staged<NHWC>& s, float4* slab, const KP& g, int ncq, int t, int T,
-                                            int p, int gl, bool active, int part) {
-  if constexpr (NHWC) {
-    if (part == 0) stage_store(s, slab, g, ncq, p, gl, active);
-    return ncq;
-  } else {
-    // part r commits block round r (plus the tails with part 0); quads whose every block has been
-    // committed so far are complete
-    stage_store<BF>(s, slab, g, ncq, t, T, part == 0, part, part + 1);
-    return part + 1 >= kRB ? ncq : min(ncq, ((part + 1) * T) / (g.P >> 2));
-  }
-}
-
 // 1 / max(sqrt(n2), eps) = min(rsqrt(n2), 1/eps): one v_rsq_f32 (1 ulp) instead of an IEEE sqrt and
 // an IEEE divide (~25 instructions on the finalize critical path); rsqrt(0) = inf -> 1/eps.
 __device__ __forceinline__ float inv_norm(float n2, float inv_eps) {
   return fminf(__builtin_amdgcn_rsqf(n2), inv_eps);
-}
-
-// ---- forward --------------------------------------------------------------------------------
-// POOL = the fused tail of models/NFP_Pooling.py:27-31: besides the neighbour maps the same pass emits
-//   gap[b,c]  = mean over pixels of x[b,c]      (AdaptiveAvgPool2d(1), NFP_Pooling.py:27)
-//   nfpm[b,n] = mean over pixels of out[b,n]    (adaptive_avg_pool2d of the NFP maps, NFP_Pooling.py:31)
-// GAP comes from the 4x4 staging blocks while they are still in registers (4-pixel partial sums,
-// one extra ds_write_b128 per block, then 13 conflict-free reads per channel quad); NCHW f32 only.
-// MAXT = workgroup size bound: 512 (2 waves/SIMD, the measured best for small maps) or 1024 for maps
-// with more than 128 pixels, where 512 threads would leave only 2-3 channel groups per image.
-template <int R, int M, bool BF, bool NHWC, bool POOL = false, int MAXT = kFwdThreads>
-__global__ void __launch_bounds__(MAXT) fwd_fast(const KP g, const void* __restrict__ x, void* __restrict__ out,
-                                                        float* __restrict__ saved, float* __restrict__ gap,
-                                                        float* __restrict__ nfpm) {
-  static_assert(!POOL || (!BF && !NHWC), "fused pooling tail: NCHW float32 only");
-  constexpr int N = Win<R>::N, NF = Win<R>::NF;
-  extern __shared__ __attribute__((aligned(16))) float4 lds4[];
-  float4* slab = lds4;
-  const int P = g.P;
-  const int b = blockIdx.x, t = threadIdx.x, T = blockDim.x;
-  const int gl = fast_div(t, g.invP), p = t - gl * P;
-  const int py = fast_div(p, g.invW), px = p - py * g.W;
-  const bool active = gl < g.G;
-  constexpr int ES = BF ? 2 : 4;
-  const Rsrc xb = make_rsrc((const char*)x + (long long)b * g.sB * ES, (long long)g.C * P * ES);  // wave-uniform
-
-  NFP_STAMP_INIT();
-  NFP_STAMP(0);
-  NFP_STAMP(6);
-  Staged<NHWC> st;
-  stage_issue<BF, NHWC>(st, xb, g, 0, min(g.Cc, g.C) >> 2, t, T, p, gl, active);
-  __builtin_amdgcn_sched_barrier(0);
-  NFP_STAMP(1);
-
-  int off[NF];
-#pragma unroll
-  for (int d = 0; d < NF; ++d) {
-    int dy, dx;
-    fdir<R>(d, dy, dx);
-    bool ok = (px + dx >= 0) && (px + dx < g.W) && (py + dy < g.H);
-    off[d] = ok ? swz(p + dy * g.W + dx) - swz(p) : 0;  // invalid pairs read the own slot: finite junk, never used
-  }
-  float acc[NF];
-#pragma unroll
-  for (int d = 0; d < NF; ++d) acc[d] = 0.f;
-  float nrm = 0.f;
-  const int Pp = (P + 3) & ~3, sp = swz(p);
-  const int NQ = P >> 2, PT = P & 3, NB = NQ + PT;  // GAP partials per channel quad
-  float4* gp = slab + (g.Cc >> 2) * Pp;             // [Cc/4][NB] (POOL only)
-
-  for (int c0 = 0; c0 < g.C; c0 += g.Cc) {
-    const int ncq = min(g.Cc, g.C - c0) >> 2;
-    if (c0 > 0) {
-      __syncthreads();  // previous chunk fully consumed
-      stage_issue<BF, NHWC>(st, xb, g, c0, ncq, t, T, p, gl, active);
-    }
-    if constexpr (POOL) {
-      // 4-pixel (block) and 1-pixel (tail) partial channel sums, straight from the staged registers
-#pragma unroll
-      for (int r = 0; r < kRB; ++r) {
-        const int i = t + r * T;
-        if (i < ncq * NQ) {
-          const int cq = fast_div(i, g.invNQ), pq = i - cq * NQ;
-          float4 s4;
-          s4.x = (st.blk[r][0].x + st.blk[r][0].y) + (st.blk[r][0].z + st.blk[r][0].w);
-          s4.y = (st.blk[r][1].x + st.blk[r][1].y) + (st.blk[r][1].z + st.blk[r][1].w);
-          s4.z = (st.blk[r][2].x + st.blk[r][2].y) + (st.blk[r][2].z + st.blk[r][2].w);
-          s4.w = (st.blk[r][3].x + st.blk[r][3].y) + (st.blk[r][3].z + st.blk[r][3].w);
-          gp[cq * NB + pq] = s4;
-        }
-      }
-#pragma unroll
-      for (int r = 0; r < kRT; ++r) {
-        const int i = t + r * T;
-        if (i < ncq * PT) {
-          const int cq = fast_div(i, g.invPT), pt = i - cq * PT;
-          gp[cq * NB + NQ + pt] = st.tl[r];
-        }
-      }
-    }
-    int done = 0;
-#pragma unroll
-    for (int part = 0; part < kRB; ++part) {
-      const int upto = stage_commit<BF, NHWC>(st, slab, g, ncq, t, T, p, gl, active, part);
-      if (upto == done) continue;  // uniform: nothing new became complete
-      __syncthreads();
-      if (part == 0) NFP_STAMP(2);
-      if (active) {
-        // this thread's quads gl, gl+G, ... inside [done, upto)
-        int cq = gl + ((max(done - gl, 0) + g.G - 1) / g.G) * g.G;
-#pragma unroll NFP_UNROLL_F
-        for (; cq < upto; cq += g.G) {
-          const float4* row = slab + cq * Pp + sp;
-          const float4 a = row[0];
-          nrm = fmaf(a.x, a.x, fmaf(a.y, a.y, fmaf(a.z, a.z, fmaf(a.w, a.w, nrm))));
-#pragma unroll
-          for (int d = 0; d < NF; ++d) {
-            const float4 q = row[off[d]];
-            if (M == NFP_COSINE) {
-              acc[d] = fmaf(a.x, q.x, fmaf(a.y, q.y, fmaf(a.z, q.z, fmaf(a.w, q.w, acc[d]))));
-            } else {
-              float e0 = a.x - q.x, e1 = a.y - q.y, e2 = a.z - q.z, e3 = a.w - q.w;
-              acc[d] = fmaf(e0, e0, fmaf(e1, e1, fmaf(e2, e2, fmaf(e3, e3, acc[d]))));
-            }
-          }
-        }
-      }
-      done = upto;
-    }
-    if constexpr (POOL) {
-      // the commits' barriers have made gp visible; one thread per channel quad, fixed order
-      for (int cq = t; cq < ncq; cq += T) {
-        float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int k = 0; k < NB; ++k) {
-          const float4 v = gp[cq * NB + k];
-          s4.x += v.x;
-          s4.y += v.y;
-          s4.z += v.z;
-          s4.w += v.w;
-        }
-        const float ip_ = g.invP;
-        *(float4*)(gap + (long long)b * g.C + c0 + 4 * cq) = make_float4(s4.x * ip_, s4.y * ip_, s4.z * ip_, s4.w * ip_);
-      }
-    }
-  }
-  // channel-group reduction through LDS, fixed order
-  __syncthreads();
-  NFP_STAMP(3);
-  float* red = (float*)lds4;             // [G][NF+1][P]
-  float* Tt = red + g.G * (NF + 1) * P;  // [NF+1][P]
-  if (active) {
-#pragma unroll
-    for (int d = 0; d < NF; ++d) red[(gl * (NF + 1) + d) * P + p] = acc[d];
-    red[(gl * (NF + 1) + NF) * P + p] = nrm;
-  }
-  __syncthreads();
-  for (int i = t; i < (NF + 1) * P; i += T) {
-    float s = 0.f;
-    for (int gg = 0; gg < g.G; ++gg) s += red[gg * (NF + 1) * P + i];
-    Tt[i] = s;
-  }
-  __syncthreads();
-  NFP_STAMP(4);
-  // outputs: thread (p, n = gl, gl+G, ...); stride-1 "same" geometry => output pixel == centre pixel
-  const float* n2 = Tt + NF * P;
-  if (active) {
-    NbrMap<R> nm;
-    nm.init(g, py, px);
-    void* ob = (char*)out + (long long)b * N * P * ES;
-    const float n2p = n2[p];
-    const float ip = inv_norm(n2p, g.inv_eps);
-    for (int n = gl; n < N; n += g.G) {
-      int qy, qx;
-      const int q = nm.get(g, n, qy, qx);
-      const int qc = max(q, 0);
-      const int dy = qy - py, dx = qx - px;
-      const bool fwd = dy > 0 || (dy == 0 && dx > 0);
-      // distinct in-image pair: the half-stencil table entry (index clamped when unused)
-      const int fi = fwd ? fidx<R>(dy, dx) : fidx<R>(-dy, -dx);
-      const bool pair_ok = q >= 0 && q != p;
-      const float pairv = Tt[(pair_ok ? fi : 0) * P + (fwd ? p : qc)];
-      const float n2q = n2[qc];
-      float v;
-      if (M == NFP_COSINE) {
-        const float s = q < 0 ? 0.f : (q == p ? n2p : pairv) * ip * inv_norm(n2q, g.inv_eps);
-        v = g.similarity ? s : 1.f - s;
-      } else {
-        float d2;
-        if (g.diff)
-          d2 = q < 0 ? n2p : (q == p ? 0.f : pairv);
-        else
-          d2 = q < 0 ? 0.f : n2q;  // 'Norm' quirk (nfp.py:74 vs 85): |neighbour|
-        const float dd = __builtin_amdgcn_sqrtf(d2);
-        v = g.similarity ? -dd : dd;
-      }
-      stx(ob, n * P + p, v, BF ? NFP_BF16 : NFP_F32);
-      if constexpr (POOL) Tt[(NF + 1) * P + n * P + p] = v;  // vm[n][p], behind the half-stencil table
-    }
-    if (M == NFP_COSINE && saved != nullptr && gl == 0) saved[(long long)b * P + p] = __builtin_amdgcn_sqrtf(n2p);
-  }
-  if constexpr (POOL) {
-    __syncthreads();
-    // wave w reduces map n = w, w + nwaves, ...: lane-strided partial sums, then a fixed shuffle tree
-    const float* vm = Tt + (NF + 1) * P;
-    const int lane = t & 63, wv = t >> 6, nw = T >> 6;
-    for (int n = wv; n < N; n += nw) {
-      float sacc = 0.f;
-      for (int i = lane; i < P; i += 64) sacc += vm[n * P + i];
-      for (int m = 32; m >= 1; m >>= 1) sacc += __shfl_xor(sacc, m);
-      if (lane == 0) nfpm[(long long)b * N + n] = sacc * g.invP;
-    }
-  }
-  NFP_STAMP(5);
 }
 
 // ---- backward phase B on the matrix cores (bf16 storage) ----------------------------------------------------

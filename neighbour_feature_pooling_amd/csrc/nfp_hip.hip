@@ -46,7 +46,7 @@ void publish_variant() {
 // Test / A-B switches, read from the environment ONCE when the library is loaded (and again only when a test
 // calls nfp_reload_env): the launch path itself never calls getenv.
 struct Switches {
-  std::atomic<int> fwd_scalar{0}, bwd_atomic{0}, bwd_bands{0}, force_generic{0}, mfma{1}, fwd_band{1};
+  std::atomic<int> fwd_scalar{0}, bwd_atomic{0}, bwd_bands{0}, force_generic{0}, mfma{1};
 };
 Switches g_sw;
 #ifndef NFP_MFMA_DEFAULT
@@ -61,7 +61,6 @@ void read_env() {
   g_sw.bwd_atomic = flag("NFP_BWD_ATOMIC", 0);
   g_sw.force_generic = flag("NFP_FORCE_GENERIC", 0);
   g_sw.mfma = flag("NFP_MFMA", NFP_MFMA_DEFAULT);
-  g_sw.fwd_band = flag("NFP_FWD_BAND", 1);
   const char* e = getenv("NFP_BWD_BANDS");
   g_sw.bwd_bands = e ? atoi(e) : 0;
 }
@@ -431,7 +430,6 @@ int launch_bwd_generic(KP g, const void* x, const void* go, const void* out, con
 #ifndef NFP_BWD_SLAB_KB
 #define NFP_BWD_SLAB_KB 60
 #endif
-constexpr int kSlabBudgetFwd = NFP_FWD_SLAB_KB * 1024;
 constexpr int kSlabBudgetBwd = NFP_BWD_SLAB_KB * 1024;
 
 bool force_generic() { return g_sw.force_generic.load(std::memory_order_relaxed) != 0; }
@@ -467,55 +465,19 @@ int even_groups(int ncq, int gmax) {
 }
 
 // channels per LDS chunk: bounded by the slab budget and by what one staging round-set can carry
-int chunk_channels(const KP& g, int total, int T, int G, bool nhwc, int budget, bool overlap_blocks = false) {
+int chunk_channels(const KP& g, int total, int T, int G, bool nhwc, int budget) {
   int ncq = budget / (((g.P + 3) & ~3) * 16);
   if (nhwc) {
     if (ncq > kRN * G) ncq = kRN * G;
-  } else if (overlap_blocks) {  // backward: ceil(P/4) blocks per channel row, no tail pixels (nfp_fast.h: StagedOvl)
+  } else {  // ceil(P/4) blocks per channel row, the last one overlapping (nfp_fast.h: StagedOvl)
     const int NQb = (g.P + 3) >> 2;
     if (ncq > (kRB * T) / NQb) ncq = (kRB * T) / NQb;
-  } else {
-    const int NQ = g.P >> 2, PT = g.P & 3;
-    if (NQ > 0 && ncq > (kRB * T) / NQ) ncq = (kRB * T) / NQ;
-    if (PT > 0 && ncq > (kRT * T) / PT) ncq = (kRT * T) / PT;
   }
   if (ncq > 2047) ncq = 2047;  // fast_div quotient bound
   if (ncq < 1) ncq = 1;
   int cmax = 4 * ncq;
   int nch = (total + cmax - 1) / cmax;
   return round4((total + nch - 1) / nch);
-}
-
-template <int R, int M, bool BF, bool NHWC, bool POOL = false, int MAXT = kFwdThreads>
-int launch_fwd_fast_t(KP g, const void* x, void* out, float* saved, hipStream_t st, float* gap = nullptr,
-                      float* nfpm = nullptr) {
-  constexpr int NF = Win<R>::NF;
-  if (MAXT == kFwdThreads && !POOL && g.P > 128)  // big maps: 1024-thread variant (more channel groups per image)
-    return launch_fwd_fast_t<R, M, BF, NHWC, false, 1024>(g, x, out, saved, st, gap, nfpm);
-  g.G = MAXT / g.P;
-  if (g.G < 1) g.G = 1;
-  if (g.G > g.C / 4) g.G = g.C / 4;
-  int T = ((g.P * g.G + 63) / 64) * 64;
-  // One workgroup per image.  Up to one image per CU the whole image slab is staged at once; beyond
-  // that, half-size slabs let two workgroups share a CU and overlap each other's phases (measured
-  // +29 % at B = 1024, -16 % at B = 64).
-  const int fbudget = g.B > 256 ? kSlabBudgetFwd / 2 : kSlabBudgetFwd;
-  // (the fused-pool variant also keeps (P/4 + P%4) partial-sum slots per channel quad)
-  const int fb = POOL ? (int)((long long)fbudget * g.P / (g.P + (g.P >> 2) + (g.P & 3) + 4)) : fbudget;
-  g.Cc = chunk_channels(g, g.C, T, g.G, NHWC, fb);
-  g.G = even_groups(g.Cc / 4, g.G);
-  T = ((g.P * g.G + 63) / 64) * 64;
-  g.Cc = chunk_channels(g, g.C, T, g.G, NHWC, fb);
-  size_t slab = (size_t)(g.Cc / 4) * ((g.P + 3) & ~3) * 16;
-  if (POOL) slab += (size_t)(g.Cc / 4) * ((g.P >> 2) + (g.P & 3)) * 16;  // GAP partials
-  size_t red = (size_t)(g.G + 1) * (NF + 1) * g.P * 4;
-  if (POOL) red += (size_t)Win<R>::N * g.P * 4;  // pooled-map staging
-  size_t lds = slab > red ? slab : red;
-  if (lds > (size_t)kLdsMax) return kNotApplicable;  // tables + slab do not fit: the generic kernels serve it
-  snprintf(g_variant, sizeof(g_variant), "fwd_fast<R%d,%s,%s,%s%s>", R, M == NFP_COSINE ? "cos" : "l2",
-           BF ? "bf16" : "f32", NHWC ? "nhwc" : "nchw", POOL ? ",pool" : "");
-  return launch("fwd_fast", fwd_fast<R, M, BF, NHWC, POOL, MAXT>, dim3(g.B), dim3(T), lds, st, g, x, out, saved, gap,
-                nfpm);
 }
 
 // Row-banded forward (nfp_band.h): needs the descriptor's workspace tables.
@@ -550,21 +512,12 @@ int launch_fwd_band_t(KP g, const void* x, void* out, float* saved, hipStream_t 
 
 template <int R, int M>
 int launch_fwd_band(const KP& g, const void* x, void* out, float* saved, hipStream_t st) {
-  if (g.ws == nullptr || g_sw.fwd_band.load(std::memory_order_relaxed) == 0) return kNotApplicable;
+  if (g.ws == nullptr) return kNotApplicable;
   const bool bf = g.dtype == NFP_BF16, nhwc = !g.contig;
   if (bf) return nhwc ? launch_fwd_band_t<R, M, true, true>(g, x, out, saved, st)
                       : launch_fwd_band_t<R, M, true, false>(g, x, out, saved, st);
   return nhwc ? launch_fwd_band_t<R, M, false, true>(g, x, out, saved, st)
               : launch_fwd_band_t<R, M, false, false>(g, x, out, saved, st);
-}
-
-template <int R, int M>
-int launch_fwd_fast(const KP& g, const void* x, void* out, float* saved, hipStream_t st) {
-  const bool bf = g.dtype == NFP_BF16, nhwc = !g.contig;
-  if (bf) return nhwc ? launch_fwd_fast_t<R, M, true, true>(g, x, out, saved, st)
-                      : launch_fwd_fast_t<R, M, true, false>(g, x, out, saved, st);
-  return nhwc ? launch_fwd_fast_t<R, M, false, true>(g, x, out, saved, st)
-              : launch_fwd_fast_t<R, M, false, false>(g, x, out, saved, st);
 }
 
 // LDS of bwd_fast's phase A: tables that live to the end of the kernel (Wt, Dt, two norm factors per pixel), and
@@ -593,10 +546,10 @@ int launch_bwd_fast_t(KP g, const void* x, const void* go, const void* out, cons
   int T = ((g.P * g.G + 63) / 64) * 64;
   // large batches (one workgroup per image, several images per CU over time): fewer, larger chunks win
   const int bbudget = (S == 1 && g.B > 256) ? 2 * kSlabBudgetBwd : kSlabBudgetBwd;
-  g.Cc = chunk_channels(g, g.Cwg, T, g.G, NHWC, bbudget, true);
+  g.Cc = chunk_channels(g, g.Cwg, T, g.G, NHWC, bbudget);
   g.G = even_groups(g.Cc / 4, g.G);
   T = ((g.P * g.G + 63) / 64) * 64;
-  g.Cc = chunk_channels(g, g.Cwg, T, g.G, NHWC, bbudget, true);
+  g.Cc = chunk_channels(g, g.Cwg, T, g.G, NHWC, bbudget);
   const size_t fixed = bwd_fixed_bytes(g, K2), pairs = bwd_pair_bytes(g, M, N);
   const size_t slab = (size_t)(g.Cc / 4) * ((g.P + 3) & ~3) * 16;
   g.early = fixed + pairs + slab <= kEarlyBudget ? 1 : 0;
@@ -761,13 +714,6 @@ int forward_impl(const nfp_desc* d, const void* x, void* out, float* saved, void
     else
       rc = g.R == 1 ? launch_fwd_band<1, NFP_NORM>(g, x, out, saved, st)
                     : launch_fwd_band<2, NFP_NORM>(g, x, out, saved, st);
-    if (rc != kNotApplicable) return rc;
-    if (g.measure == NFP_COSINE)
-      rc = g.R == 1 ? launch_fwd_fast<1, NFP_COSINE>(g, x, out, saved, st)
-                    : launch_fwd_fast<2, NFP_COSINE>(g, x, out, saved, st);
-    else
-      rc = g.R == 1 ? launch_fwd_fast<1, NFP_NORM>(g, x, out, saved, st)
-                    : launch_fwd_fast<2, NFP_NORM>(g, x, out, saved, st);
     if (rc != kNotApplicable) return rc;
   }
   switch (g.measure) {

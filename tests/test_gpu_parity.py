@@ -61,15 +61,13 @@ def _supported(c):
     return c["ctor"]["measure"].lower() in HIP_MEASURES
 
 
-@pytest.fixture(params=["auto", "whole", "generic", "atomic"])
+@pytest.fixture(params=["auto", "generic", "atomic"])
 def variant(request, monkeypatch):
-    """'auto' = the dispatcher's choice (hot-path kernels where they apply); 'whole' = the same with the row-banded
-    forward switched off (fwd_fast: one workgroup per image, the fused-pooling kernel's base); 'generic' forces the
+    """'auto' = the dispatcher's choice (hot-path kernels where they apply); 'generic' forces the
     any-geometry kernels of nfp_gather.h (fwd_pairs / bwd_gather); 'atomic' (the switches' historical name) forces
     the table-free kernels of last resort (nfp_direct.h) that serve maps too large for those kernels' LDS tables — every
     implementation is held to the same bar on every case."""
-    nfp_switch(monkeypatch, "NFP_FORCE_GENERIC", "0" if request.param in ("auto", "whole") else "1")
-    nfp_switch(monkeypatch, "NFP_FWD_BAND", "0" if request.param == "whole" else "1")
+    nfp_switch(monkeypatch, "NFP_FORCE_GENERIC", "0" if request.param == "auto" else "1")
     nfp_switch(monkeypatch, "NFP_BWD_ATOMIC", "1" if request.param == "atomic" else "0")
     nfp_switch(monkeypatch, "NFP_FWD_SCALAR", "1" if request.param == "atomic" else "0")
     nfp_switch(monkeypatch, "NFP_BWD_BANDS", None)
