@@ -91,6 +91,13 @@ typedef struct nfp_desc {
                                 nfp_workspace_init, or NULL.  The hot-path kernels (stride 1,
                                 pad = R, cosine / L2) read their index maps from it; without it
                                 the call is served by the general kernels                   */
+  int32_t inner_R;           /* 0, or 1 with R = 2: ALSO produce the maps of radius 1 (padding 1)
+                                from the same pass — models/nfp_heads.py:80-118 concatenates
+                                NFP(R=1, padding=1) and NFP(R=2, padding=2) of one feature map.
+                                out / grad_out are then [B, 8 + 24, H, W], the 8 maps of radius 1
+                                first (torch.cat order).  Hot-path descriptors only (cosine / L2,
+                                stride 1, padding = R, workspace set)                      */
+  int32_t reserved_;         /* 0                                                           */
 } nfp_desc;
 
 int nfp_abi_version(void);

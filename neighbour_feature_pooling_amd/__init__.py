@@ -3,12 +3,14 @@
 Drop-in for the reference's NFP hot path:
     NFPPooling, EnhancedNFPPooling   <- models/pooling/nfp.py::NFPPooling
     nfp_pooling                      <- models/NFP_Pooling.py::nfp_pooling
+    MultiRadiusNFPPooling            <- the per-radius layers + concatenation of models/nfp_heads.py::MultiRadiusNFPHead
     nfp_op, nfp_pool, NfpConfig      functional forms (autograd ops over libnfp_hip.so)
 """
-from .functional import NfpConfig, nfp_pool
+from .functional import NfpConfig, nfp_multi_radius, nfp_pool
 from .functional import nfp as nfp_op  # (`nfp` itself is the submodule holding NFPPooling)
-from .nfp import EnhancedNFPPooling, NFPPooling
+from .nfp import EnhancedNFPPooling, MultiRadiusNFPPooling, NFPPooling
 from .pooling import nfp_pooling
 
-__all__ = ["NFPPooling", "EnhancedNFPPooling", "nfp_pooling", "nfp_op", "nfp_pool", "NfpConfig"]
-__version__ = "0.1.0"
+__all__ = ["NFPPooling", "EnhancedNFPPooling", "MultiRadiusNFPPooling", "nfp_pooling", "nfp_op", "nfp_pool",
+           "nfp_multi_radius", "NfpConfig"]
+__version__ = "0.2.0"

@@ -28,7 +28,7 @@ class NfpDesc(ctypes.Structure):
                 ("B", "C", "H", "W", "R", "pad", "stride", "dilation", "pad_mode", "measure",
                  "similarity", "diff_weights", "dtype")] + \
                [("p", ctypes.c_float), ("eps", ctypes.c_float), ("q_scs", ctypes.c_float)] + \
-               [(n, ctypes.c_int64) for n in ("sxB", "sxC", "sxH", "sxW", "sgB")] + [("ws", ctypes.c_void_p)]
+               [(n, ctypes.c_int64) for n in ("sxB", "sxC", "sxH", "sxW", "sgB")] + [("ws", ctypes.c_void_p), ("inner_R", ctypes.c_int32), ("reserved_", ctypes.c_int32)]
 
 
 class NfpError(RuntimeError):

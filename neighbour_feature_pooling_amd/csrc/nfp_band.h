@@ -30,6 +30,8 @@ template <int R>
 struct FoffQ {
   static constexpr int v = ((Win<R>::NF + 7) & ~7) / 8;  // 16-byte pieces of a pixel's foff row (ws_layout: FR)
 };
+// (template parameter R of fwd_band: the radius SPEC of nfp_tables.h::Win — 1, 2, or 12 for radii 1 and 2 together;
+// the window radius itself is g.R)
 
 // POOL = the fused tail of models/NFP_Pooling.py:27-31 (one band = the whole image): besides the neighbour maps the
 // same pass emits  gap[b,c] = mean over pixels of x[b,c]  (AdaptiveAvgPool2d(1), NFP_Pooling.py:27) and
@@ -47,7 +49,7 @@ __global__ void __launch_bounds__(kBandT) fwd_band(const KP g, const void* __res
   const int b = blockIdx.x, band = blockIdx.y, t = threadIdx.x;
   constexpr int T = kBandT;
   // rows: owned [y0, y1), staged [y0, ye); pixels: owned [p0, po), staged [p0, pe)
-  const int y0 = band * rb, y1 = min(g.H, y0 + rb), ye = min(g.H, y1 + R);
+  const int y0 = band * rb, y1 = min(g.H, y0 + rb), ye = min(g.H, y1 + g.R);
   const int p0 = y0 * W, po = y1 * W, pe = ye * W, Ps = pe - p0;
   const int base = p0 & ~7;                      // slot origin of the band's slab rows
   const int Ppb = ((pe + 3) & ~3) - base;        // slots per slab row (one channel quad)

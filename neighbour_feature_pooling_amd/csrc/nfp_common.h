@@ -17,6 +17,7 @@ namespace nfp {
 struct KP {
   int B, C, H, W, P;  // P = H*W input pixels per channel
   int R, k, N, pad, stride, dil, mode;
+  int rs;  // radius spec of the hot-path kernels (nfp_tables.h::Win): R, or 12 = radii 1 and 2 from one pass
   int Ho, Wo, O;  // O = Ho*Wo outputs per neighbour map
   int measure, similarity, diff, dtype;
   int godtype;  // dtype of the grad_out the backward kernel reads (f32 scratch for Attention)

@@ -369,7 +369,7 @@ __global__ void __launch_bounds__(GEMM ? 1024 : kBwdThreads) bwd_fast(const KP g
   constexpr int K2 = Win<R>::K2, N = Win<R>::N;
   // the diagonal is folded by a phase of its own when the weights are consumed as a table (matrix cores) or the
   // window is large; for k = 3 every compute thread folds its own pixel's nine terms while it loads its weights
-  constexpr bool FOLD_PHASE = GEMM || R != 1;
+  constexpr bool FOLD_PHASE = GEMM || Win<R>::RAD != 1;  // (R: radius spec of nfp_tables.h::Win)
   extern __shared__ __attribute__((aligned(16))) float4 lds4[];
   const int P = g.P;
   // LDS: Wt | Dt | ipn | dfn (live to the end) | pair values | x slab.  The slab lies OVER the pair values (dead
@@ -406,7 +406,7 @@ __global__ void __launch_bounds__(GEMM ? 1024 : kBwdThreads) bwd_fast(const KP g
   // gathered — the pairs that link r with the pixel t under slot j are the pairs that link t with r under its slot
   // K2-1-j, so each sum is stored twice.  k = 3 has fewer entries than threads: every slot is gathered by its own
   // thread.
-  constexpr bool SYM = R >= 2;
+  constexpr bool SYM = Win<R>::RAD >= 2;
   constexpr int NJ = SYM ? Win<R>::NF + 1 : K2;
   const int NE = P * NJ, NO = N * P;
   auto entry_of = [&](int e2, int& r, int& j) {  // gathered entry e2 -> (pixel, slot); returns its table row
@@ -524,7 +524,7 @@ __global__ void __launch_bounds__(GEMM ? 1024 : kBwdThreads) bwd_fast(const KP g
       // costs an LDS round trip each; k = 5 (ten entries per thread, most of them two links long): skip the rest
       take(r0.x & 0xFFFFu);
       take(r0.x >> 16);
-      if (R == 1 || live(r0.y)) {
+      if (Win<R>::RAD == 1 || live(r0.y)) {
         take(r0.y & 0xFFFFu);
         take(r0.y >> 16);
         take(r0.z & 0xFFFFu);

@@ -108,6 +108,14 @@ int make_kp(const nfp_desc* d, KP* g) {
   memset(g, 0, sizeof(*g));
   g->B = d->B; g->C = d->C; g->H = d->H; g->W = d->W; g->P = d->H * d->W;
   g->R = d->R; g->k = k; g->N = k * k - 1; g->pad = d->pad; g->stride = d->stride; g->dil = d->dilation;
+  g->rs = d->R;
+  if (d->inner_R != 0) {
+    // both radii from one pass (nfp_heads.py:80-118): the hot-path kernels only, radii (1, 2), "same" maps
+    if (d->inner_R != 1 || d->R != 2 || d->pad != 2 || d->stride != 1 || d->dilation != 1)
+      return fail(NFP_E_UNSUPPORTED, "multi-radius: radii (1, 2) with padding = R, stride 1, dilation 1 only");
+    g->rs = 12;
+    g->N = (k * k - 1) + 8;
+  }
   g->mode = d->pad_mode;
   g->Ho = (d->H + 2 * d->pad - span) / d->stride + 1;
   g->Wo = (d->W + 2 * d->pad - span) / d->stride + 1;
@@ -504,7 +512,7 @@ int launch_fwd_band_t(KP g, const void* x, void* out, float* saved, hipStream_t 
   const size_t red = (size_t)(kBandT + psm) * (NF + 1) * 4 + (POOL ? (size_t)Win<R>::N * psm * 4 : 0);
   const size_t lds = std::max(slab, red);
   if (lds > (size_t)kLdsMax) return kNotApplicable;
-  snprintf(g_variant, sizeof(g_variant), "fwd_band<R%d,%s,%s,%s%s>x%d", R, M == NFP_COSINE ? "cos" : "l2",
+  snprintf(g_variant, sizeof(g_variant), "fwd_band<R%s,%s,%s,%s%s>x%d", R == 12 ? "1+2" : (R == 1 ? "1" : "2"), M == NFP_COSINE ? "cos" : "l2",
            BF ? "bf16" : "f32", NHWC ? "nhwc" : "nchw", POOL ? ",pool" : "", nb);
   return launch("fwd_band", fwd_band<R, M, BF, NHWC, POOL>, dim3(g.B, nb), dim3(kBandT), lds, st, g, x, out, saved, g.ws,
                 rb, gap, nfpm);
@@ -555,8 +563,8 @@ int launch_bwd_fast_t(KP g, const void* x, const void* go, const void* out, cons
   g.early = fixed + pairs + slab <= kEarlyBudget ? 1 : 0;
   const size_t lds = g.early ? fixed + pairs + slab : fixed + std::max(pairs, slab);
   if (lds > (size_t)kLdsMax) return kNotApplicable;  // tables + slab do not fit: the generic kernels serve it
-  snprintf(g_variant, sizeof(g_variant), "bwd_fast<R%d,%s,%s,%s%s>", R, M == NFP_COSINE ? "cos" : "l2",
-           BF ? "bf16" : "f32", NHWC ? "nhwc" : "nchw", POOL ? ",pool" : "");
+  snprintf(g_variant, sizeof(g_variant), "bwd_fast<R%s,%s,%s,%s%s>", R == 12 ? "1+2" : (R == 1 ? "1" : "2"),
+           M == NFP_COSINE ? "cos" : "l2", BF ? "bf16" : "f32", NHWC ? "nhwc" : "nchw", POOL ? ",pool" : "");
   return launch("bwd_fast", bwd_fast<R, M, BF, NHWC, POOL>, dim3(g.B, S), dim3(T), lds, st, g, x, go, out, saved, gx,
                 ggap, gnfpm, g.ws);
 }
@@ -625,6 +633,17 @@ int launch_bwd_gemm_t(KP g, const void* x, const void* go, const void* out, cons
                 saved, gx, ggap, gnfpm, g.ws);
 }
 
+// the vector (VALU) backward, for any radius spec
+template <int R, int M>
+int launch_bwd_vec(const KP& g, const void* x, const void* go, const void* out, const float* saved, void* gx,
+                   hipStream_t st) {
+  const bool bf = g.dtype == NFP_BF16, nhwc = !g.contig;
+  if (bf) return nhwc ? launch_bwd_fast_t<R, M, true, true>(g, x, go, out, saved, gx, st)
+                      : launch_bwd_fast_t<R, M, true, false>(g, x, go, out, saved, gx, st);
+  return nhwc ? launch_bwd_fast_t<R, M, false, true>(g, x, go, out, saved, gx, st)
+              : launch_bwd_fast_t<R, M, false, false>(g, x, go, out, saved, gx, st);
+}
+
 template <int R, int M>
 int launch_bwd_fast(const KP& g, const void* x, const void* go, const void* out, const float* saved, void* gx,
                     hipStream_t st) {
@@ -634,10 +653,7 @@ int launch_bwd_fast(const KP& g, const void* x, const void* go, const void* out,
                         : launch_bwd_gemm_t<R, M, false>(g, x, go, out, saved, gx, st);
     if (rc != kNotApplicable) return rc;
   }
-  if (bf) return nhwc ? launch_bwd_fast_t<R, M, true, true>(g, x, go, out, saved, gx, st)
-                      : launch_bwd_fast_t<R, M, true, false>(g, x, go, out, saved, gx, st);
-  return nhwc ? launch_bwd_fast_t<R, M, false, true>(g, x, go, out, saved, gx, st)
-              : launch_bwd_fast_t<R, M, false, false>(g, x, go, out, saved, gx, st);
+  return launch_bwd_vec<R, M>(g, x, go, out, saved, gx, st);
 }
 
 }  // namespace
@@ -699,6 +715,14 @@ int forward_impl(const nfp_desc* d, const void* x, void* out, float* saved, void
   if (!x || !out) return fail(NFP_E_INVALID, "null tensor pointer");
   if (g.B == 0) return NFP_OK;
   hipStream_t st = (hipStream_t)hip_stream;
+  if (g.rs == 12) {
+    if (g.ws == nullptr || !fast_ok(g, x, x))
+      return fail(NFP_E_UNSUPPORTED, "multi-radius: cosine / L2 on maps of at most %d pixels, C %% 4 == 0, dense layout, "
+                  "descriptor with a workspace", kBwdThreads);
+    const int rc = g.measure == NFP_COSINE ? launch_fwd_band<12, NFP_COSINE>(g, x, out, saved, st)
+                                           : launch_fwd_band<12, NFP_NORM>(g, x, out, saved, st);
+    return rc == kNotApplicable ? fail(NFP_E_UNSUPPORTED, "multi-radius: the map does not fit the hot-path forward") : rc;
+  }
   if (fast_ok(g, x, x)) {
     int rc;
     if (g.measure == NFP_COSINE)
@@ -763,6 +787,14 @@ int backward_impl(const nfp_desc* d, const void* x, const void* grad_out, const 
   if ((stats_of(g.measure) > 0 || g.measure == NFP_ATTENTION) && !saved) return fail(NFP_E_INVALID, "measure %d needs the saved state of nfp_forward", g.measure);
   if (g.B == 0) return NFP_OK;
   hipStream_t st = (hipStream_t)hip_stream;
+  if (g.rs == 12) {
+    if (g.ws == nullptr || !fast_ok(g, x, grad_x))
+      return fail(NFP_E_UNSUPPORTED, "multi-radius: cosine / L2 on maps of at most %d pixels, C %% 4 == 0, dense layout, "
+                  "descriptor with a workspace", kBwdThreads);
+    const int rc = g.measure == NFP_COSINE ? launch_bwd_vec<12, NFP_COSINE>(g, x, grad_out, out, saved, grad_x, st)
+                                           : launch_bwd_vec<12, NFP_NORM>(g, x, grad_out, out, saved, grad_x, st);
+    return rc == kNotApplicable ? fail(NFP_E_UNSUPPORTED, "multi-radius: the map does not fit the hot-path backward") : rc;
+  }
   if (g.ws != nullptr && fast_ok(g, x, grad_x)) {
     int rc;
     if (g.measure == NFP_COSINE)
@@ -847,26 +879,32 @@ static int max_links(const KP& g) {
   };
   const int K = g.k, R = g.R;
   // per axis: cnt[a][b] = taps d in [-R, R] with fold(a + d) == b
-  auto axis = [&](int n, std::vector<int>& cnt) {
+  auto axis = [&](int n, int rad, std::vector<int>& cnt) {
     cnt.assign((size_t)n * n, 0);
     for (int a = 0; a < n; ++a)
-      for (int dd = -R; dd <= R; ++dd) {
+      for (int dd = -rad; dd <= rad; ++dd) {
         const int f = fold(a + dd, n);
         if (f >= 0) cnt[(size_t)a * n + f]++;
       }
   };
-  std::vector<int> cy, cx;
-  axis(g.H, cy);
-  axis(g.W, cx);
+  std::vector<int> cy, cx, iy, ix;  // taps of the window radius; of the inner radius 1 when both are produced
+  axis(g.H, R, cy);
+  axis(g.W, R, cx);
+  if (g.rs == 12) {
+    axis(g.H, 1, iy);
+    axis(g.W, 1, ix);
+  }
   int best = 0;
   for (int ry = 0; ry < g.H; ++ry)
     for (int ty = std::max(0, ry - R); ty <= std::min(g.H - 1, ry + R); ++ty)
       for (int rx = 0; rx < g.W; ++rx)
         for (int tx = std::max(0, rx - R); tx <= std::min(g.W - 1, rx + R); ++tx) {
           if (ry == ty && rx == tx) continue;
-          const int a = cy[(size_t)ry * g.H + ty] * cx[(size_t)rx * g.W + tx];  // taps of r that read t
-          const int b = cy[(size_t)ty * g.H + ry] * cx[(size_t)tx * g.W + rx];  // taps of t that read r
-          best = std::max(best, a + b);
+          int n = cy[(size_t)ry * g.H + ty] * cx[(size_t)rx * g.W + tx]     // taps of r that read t
+                  + cy[(size_t)ty * g.H + ry] * cx[(size_t)tx * g.W + rx];  // taps of t that read r
+          if (g.rs == 12)
+            n += iy[(size_t)ry * g.H + ty] * ix[(size_t)rx * g.W + tx] + iy[(size_t)ty * g.H + ry] * ix[(size_t)tx * g.W + rx];
+          best = std::max(best, n);
         }
   (void)K;
   return best;
@@ -876,7 +914,7 @@ int64_t nfp_workspace_bytes(const nfp_desc* d) {
   KP g;
   if (make_kp(d, &g)) return -1;
   if (!fast_geometry(g)) return 0;
-  const WsLayout L = ws_layout(g.P, g.R, g.mode);
+  const WsLayout L = ws_layout(g.P, g.rs, g.mode);
   if (max_links(g) > L.LW) return 0;
   return (int64_t)L.bytes;
 }
@@ -888,6 +926,7 @@ int nfp_workspace_init(const nfp_desc* d, void* ws, void* hip_stream) {
   if (!ws || ((uintptr_t)ws & 15)) return fail(NFP_E_INVALID, "workspace pointer must be non-null and 16-byte aligned");
   hipStream_t st = (hipStream_t)hip_stream;
   const int items = g.P * g.k * g.k, blocks = std::min(64, (items + 255) / 256);
+  if (g.rs == 12) return launch("#fill_workspace", fill_workspace<12>, dim3(blocks), dim3(256), 0, st, g, (unsigned char*)ws);
   return g.R == 1 ? launch("#fill_workspace", fill_workspace<1>, dim3(blocks), dim3(256), 0, st, g, (unsigned char*)ws)
                   : launch("#fill_workspace", fill_workspace<2>, dim3(blocks), dim3(256), 0, st, g, (unsigned char*)ws);
 }
@@ -927,7 +966,7 @@ int nfp_pool_supported(const nfp_desc* d) {
   if (make_kp(d, &g)) return 0;
   // hot-path geometry (either layout, float32 or bf16) with its workspace tables; the backward's tables must fit LDS.
   // Pointer alignment is the caller's: channels-last maps need 16-byte aligned images (as nfp_forward's hot path).
-  if (g.ws == nullptr || !fast_ok(g, nullptr, nullptr)) return 0;
+  if (g.ws == nullptr || g.rs == 12 || !fast_ok(g, nullptr, nullptr)) return 0;
   const int K2 = g.k * g.k;
   const size_t bwd_tables = bwd_fixed_bytes(g, K2) + bwd_pair_bytes(g, g.measure, g.N);
   return bwd_tables + 64 <= (size_t)kLdsMax ? 1 : 0;  // the x slab shares the pair values' region (dead by then)

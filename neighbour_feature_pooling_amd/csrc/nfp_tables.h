@@ -25,10 +25,33 @@
 
 namespace nfp {
 
+// Window / tap set of a kernel instantiation.  R = 1, 2: one radius, N = K*K - 1 taps in row-major order with the
+// centre skipped (nfp.py:64-67).  R = 12: radii 1 AND 2 from one pass (the multi-radius head, nfp_heads.py:80-118,
+// concatenates NFP(R=1, padding=1) and NFP(R=2, padding=2) of the same map): window of radius 2, 8 + 24 taps, the 8
+// taps of the inner radius first — the order of torch.cat([nfp_R1(x), nfp_R2(x)], dim=1).
 template <int R>
 struct Win {
-  static constexpr int K = 2 * R + 1, K2 = K * K, N = K2 - 1, NF = N / 2;
+  static constexpr int RAD = R, K = 2 * R + 1, K2 = K * K, N = K2 - 1, NF = N / 2, NI = 0;
 };
+template <>
+struct Win<12> {
+  static constexpr int RAD = 2, K = 5, K2 = 25, N = 32, NF = 12, NI = 8;  // NI: taps of the inner radius (1)
+};
+// (dy, dx) of tap n
+template <int RS>
+__host__ __device__ inline void tap_offset(int n, int& dy, int& dx) {
+  constexpr int NI = Win<RS>::NI;
+  if (n < NI) {  // inner radius 1
+    const int tp = n + (n >= 4 ? 1 : 0);
+    dy = tp / 3 - 1;
+    dx = tp % 3 - 1;
+  } else {
+    constexpr int K = Win<RS>::K, RAD = Win<RS>::RAD;
+    const int m = n - NI, tp = m + (m >= (K * K) / 2 ? 1 : 0);
+    dy = tp / K - RAD;
+    dx = tp % K - RAD;
+  }
+}
 
 // forward direction d in [0, NF): (0,1..R), then rows dy=1..R with dx=-R..R
 template <int R>
@@ -92,11 +115,14 @@ __host__ __device__ inline long long ws_up16(long long v) { return (v + 15) & ~1
 // Links per (pixel, slot): an in-image pair is linked by one tap of each end, plus the taps the padding folds onto
 // it.  Zeros: 2.  Reflect: each axis folds at most 2 taps together, <= 4 + 4.  Replicate with R = 2 folds up to 3
 // per axis at a corner and 5 on a one-pixel-wide map: <= 15.  (nfp_workspace_bytes checks the bound by enumeration.)
-__host__ __device__ inline int ws_link_width(int mode, int R) { return (mode == NFP_PAD_REPLICATE && R >= 2) ? 16 : 8; }
-__host__ __device__ inline WsLayout ws_layout(int P, int R, int mode) {
-  const int K = 2 * R + 1, K2 = K * K, N = K2 - 1, NF = N / 2;
+// Both radii together: the links of both tap sets, <= 16 for zeros / reflect (replicate would need 23: no tables).
+__host__ __device__ inline int ws_link_width(int mode, int rs) {
+  return (rs == 12 || (mode == NFP_PAD_REPLICATE && rs >= 2)) ? 16 : 8;
+}
+__host__ __device__ inline WsLayout ws_layout(int P, int rs, int mode) {  // rs: radius spec (1, 2, or 12 = 1 and 2)
+  const int R = rs == 12 ? 2 : rs, K = 2 * R + 1, K2 = K * K, N = K2 - 1 + (rs == 12 ? 8 : 0), NF = (K2 - 1) / 2;
   WsLayout L;
-  L.LW = ws_link_width(mode, R);
+  L.LW = ws_link_width(mode, rs);
   L.BR = (K2 + 7) & ~7;
   L.FR = (NF + 7) & ~7;
   long long o = 0;
@@ -111,10 +137,10 @@ __host__ __device__ inline WsLayout ws_layout(int P, int R, int mode) {
 }
 
 // One launch fills every section (grid-stride over the largest, P*K2 items).  Stride 1, dilation 1, pad = R.
-template <int R>
+template <int RS>
 __global__ void __launch_bounds__(256) fill_workspace(const KP g, unsigned char* __restrict__ ws) {
-  constexpr int K = Win<R>::K, K2 = Win<R>::K2, N = Win<R>::N, NF = Win<R>::NF;
-  const WsLayout L = ws_layout(g.P, R, g.mode);
+  constexpr int R = Win<RS>::RAD, K = Win<RS>::K, K2 = Win<RS>::K2, N = Win<RS>::N, NF = Win<RS>::NF;
+  const WsLayout L = ws_layout(g.P, RS, g.mode);
   uint16_t* lnk = (uint16_t*)(ws + L.lnk);
   uint16_t* tq = (uint16_t*)(ws + L.tq);
   uint32_t* mask = (uint32_t*)(ws + L.mask);
@@ -124,8 +150,9 @@ __global__ void __launch_bounds__(256) fill_workspace(const KP g, unsigned char*
   const int P = g.P, W = g.W, H = g.H;
   const int stride = gridDim.x * blockDim.x, t0 = blockIdx.x * blockDim.x + threadIdx.x;
   auto nbr = [&](int p, int n) {  // mapped neighbour pixel of tap n of pixel p, -1 = zero padding
-    const int tp = n + (n >= K2 / 2 ? 1 : 0);
-    const int y = map_index(p / W + tp / K - R, H, g.mode), x = map_index(p % W + tp % K - R, W, g.mode);
+    int dy, dx;
+    tap_offset<RS>(n, dy, dx);
+    const int y = map_index(p / W + dy, H, g.mode), x = map_index(p % W + dx, W, g.mode);
     return (y < 0 || x < 0) ? -1 : y * W + x;
   };
   for (int e = t0; e < P * K2; e += stride) {

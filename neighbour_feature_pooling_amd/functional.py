@@ -29,6 +29,8 @@ class NfpConfig:
     eps: float = 1e-6
     q_scs: float = 1e-6
     diff_weights: bool = True      # raw measure string in ['norm','rmse','mahalanobis'] (nfp.py:74)
+    inner_R: int = 0               # 1 with R = 2: also the maps of radius 1 (padding 1), first in the channel axis —
+                                   # the concatenation models/nfp_heads.py:80-118 builds from two layers
 
     @property
     def kernel_size(self):
@@ -36,7 +38,7 @@ class NfpConfig:
 
     @property
     def out_channels(self):
-        return self.kernel_size ** 2 - 1
+        return self.kernel_size ** 2 - 1 + ((2 * self.inner_R + 1) ** 2 - 1 if self.inner_R else 0)
 
 
 _DTYPES = {torch.float32: _abi.F32, torch.bfloat16: _abi.BF16}
@@ -91,6 +93,7 @@ def make_desc(x, cfg, layout=None):
     d.p, d.eps, d.q_scs = float(cfg.p), float(cfg.eps), float(cfg.q_scs)
     d.sxB, d.sxC, d.sxH, d.sxW = _canonical_strides(x, layout)
     d.sgB = d.C * d.H * d.W          # grad_x is always allocated dense, in x's inner layout
+    d.inner_R = int(cfg.inner_R)
     return d
 
 
@@ -109,7 +112,7 @@ def _workspace(d, device):
     None.  They depend on the geometry only, so every call with the same map size and kernel shares one buffer per
     device; the fill kernel is enqueued once, on the current stream (allocations made under a side stream or a graph
     capture stay valid for later streams: the buffer is never freed while it is cached)."""
-    key = (device.index, d.H, d.W, d.R, d.pad, d.stride, d.dilation, d.pad_mode)
+    key = (device.index, d.H, d.W, d.R, d.pad, d.stride, d.dilation, d.pad_mode, d.inner_R)
     ws = _WORKSPACES.get(key)
     if ws is None:
         L = _abi.load()
@@ -297,6 +300,23 @@ def nfp_pool(x, cfg):
     return x.mean((2, 3)), nfp(x, cfg).mean((2, 3))
 
 
+def nfp_multi_radius(x, cfg1, cfg2):
+    """torch.cat([NFP_R1(x), NFP_R2(x)], dim=1) for two configurations that differ only in R / padding (radii 1 and 2,
+    padding = R): what MultiRadiusNFPHead.forward computes with two layers (models/nfp_heads.py:109-110).  On the GPU
+    both radii come from ONE pass over x (and one backward pass) where the hot-path kernels serve the map; otherwise
+    the two maps are computed one after the other."""
+    import dataclasses
+    fusable = (x.is_cuda and x.dim() == 4 and cfg1.R == 1 and cfg2.R == 2 and cfg1.padding == 1 and cfg2.padding == 2
+               and dataclasses.replace(cfg1, R=2, padding=2) == cfg2 and cfg2.inner_R == 0
+               and cfg2.measure in ("cosine", "norm"))
+    if fusable:
+        try:
+            return nfp(x, dataclasses.replace(cfg2, inner_R=1))
+        except _abi.NfpUnsupported:
+            pass
+    return torch.cat([nfp(x, cfg1), nfp(x, cfg2)], dim=1)
+
+
 def nfp(x, cfg):
     """[B,C,H,W] -> [B, k*k-1, H', W'] neighbour-similarity maps (NFPPooling.forward, nfp.py:132-134)."""
     if x.dim() != 4:
@@ -312,4 +332,8 @@ def nfp(x, cfg):
         return nfp_host(x, cfg)
     if x.is_cuda:
         return _NfpHip.apply(x, cfg, x.requires_grad and torch.is_grad_enabled())
+    if cfg.inner_R:
+        import dataclasses
+        return torch.cat([nfp_host(x, dataclasses.replace(cfg, R=cfg.inner_R, padding=cfg.inner_R, inner_R=0)),
+                          nfp_host(x, dataclasses.replace(cfg, inner_R=0))], dim=1)
     return nfp_host(x, cfg)

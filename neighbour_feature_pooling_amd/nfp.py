@@ -10,7 +10,7 @@ import torch
 import torch.nn as nn
 
 from . import _abi
-from .functional import NfpConfig, nfp
+from .functional import NfpConfig, nfp, nfp_multi_radius
 
 _DISPATCH = set(_abi.MEASURES) | set(_abi.MEASURE_ALIASES)
 
@@ -128,3 +128,26 @@ class EnhancedNFPPooling(NFPPooling):
         known = {k: kw[k] for k in ('p', 'stride', 'dilation', 'bias', 'padding_mode', 'similarity',
                                     'eps', 'input_size', 'q_scs') if k in kw}
         super().__init__(in_channels, R=R, measure=measure, padding=padding, **known)
+
+
+class MultiRadiusNFPPooling(nn.Module):
+    """The NFP part of models/nfp_heads.py::MultiRadiusNFPHead (nfp_heads.py:80-118): one EnhancedNFPPooling per radius
+    on the SAME feature map, concatenated along the channel axis (nfp_heads.py:88-93, 109-110).  `nfp_blocks` holds the
+    per-radius layers exactly as the reference's ModuleList does (so state dicts line up); forward() returns
+    torch.cat([blk(x) for blk in nfp_blocks], dim=1) — for R_list = (1, 2) on the GPU from one fused pass over x."""
+
+    def __init__(self, in_channels, R_list=(1, 2), measure="cosine", **kw):
+        super().__init__()
+        self.nfp_blocks = nn.ModuleList([EnhancedNFPPooling(in_channels=in_channels, R=R, measure=measure, padding=R, **kw)
+                                         for R in R_list])
+        self.in_channels = in_channels
+        self.out_channels = sum(b.out_channels for b in self.nfp_blocks)
+
+    def forward(self, x):
+        blocks = list(self.nfp_blocks)
+        if len(blocks) == 2 and all(isinstance(b, NFPPooling) for b in blocks):
+            if x.dim() == 4 and x.shape[1] != self.in_channels:
+                raise RuntimeError(f"MultiRadiusNFPPooling expected input with {self.in_channels} channels, "
+                                   f"got {x.shape[1]} channels instead")
+            return nfp_multi_radius(x, blocks[0].config, blocks[1].config)
+        return torch.cat([b(x) for b in blocks], dim=1)

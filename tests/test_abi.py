@@ -38,8 +38,9 @@ def test_abi_version_matches_header(lib):
 
 
 def test_desc_layout_matches_header():
-    # 13 int32 + 3 float + 5 int64 + 1 pointer, naturally aligned
-    assert ctypes.sizeof(_abi.NfpDesc) == 13 * 4 + 3 * 4 + 5 * 8 + 8
+    # 13 int32 + 3 float + 5 int64 + 1 pointer + 2 int32, naturally aligned
+    assert ctypes.sizeof(_abi.NfpDesc) == 13 * 4 + 3 * 4 + 5 * 8 + 8 + 8
+    assert _abi.NfpDesc.inner_R.offset == 112
     assert _abi.NfpDesc.sxB.offset == 64
     assert _abi.NfpDesc.sgB.offset == 96
     assert _abi.NfpDesc.ws.offset == 104

@@ -1002,3 +1002,70 @@ def test_direct_kernels_serve_what_no_table_kernel_can(dev):
         gref, = torch.autograd.grad(ref, x64, go.double())
         assert rel_err(out.detach().cpu().numpy(), ref.detach().cpu().numpy()) <= 1e-4, (fv, bv)
         assert rel_err(gx.cpu().numpy(), gref.cpu().numpy()) <= 2e-4, (fv, bv)
+
+
+# ---- both radii from one pass (models/nfp_heads.py:80-118) ---------------------------------------------------------
+
+@pytest.mark.parametrize("shape,measure,mode,dtype,layout", [
+    ((64, 512, 7, 7), "cosine", "reflect", torch.float32, "nchw"),      # the head's call shape (in_c = 512, 7x7)
+    ((5, 64, 7, 7), "cosine", "reflect", torch.float32, "nhwc"),
+    ((3, 48, 14, 14), "norm", "reflect", torch.float32, "nchw"),
+    ((2, 24, 5, 6), "cosine", "zeros", torch.float32, "nchw"),
+    ((2, 16, 3, 3), "cosine", "reflect", torch.float32, "nchw"),        # reflect folds taps onto the pixel itself
+    ((4, 64, 7, 7), "cosine", "reflect", torch.bfloat16, "nhwc"),
+])
+def test_multi_radius_fused_matches_oracle_concatenation(shape, measure, mode, dtype, layout, dev, oracle_lib):
+    """MultiRadiusNFPPooling(R_list=(1, 2)) on the GPU: one forward and one backward kernel produce
+    cat([NFP_R1(x), NFP_R2(x)]) and its gradient; against the oracle run once per radius."""
+    from neighbour_feature_pooling_amd import MultiRadiusNFPPooling, _abi
+    from neighbour_feature_pooling_amd.synth import feature_map
+    kw = dict(padding_mode=mode)
+    if measure == "norm":
+        kw["p"] = 2
+    m = MultiRadiusNFPPooling(shape[1], R_list=(1, 2), measure=measure, **kw)
+    bf = dtype == torch.bfloat16
+    xh = feature_map(shape, 71)
+    goh = feature_map((shape[0], 32, shape[2], shape[3]), 72)
+    if bf:
+        xh, goh = K._bf16_round(xh), K._bf16_round(goh)
+    x = torch.from_numpy(xh).to(dev).to(dtype)
+    if layout == "nhwc":
+        x = x.contiguous(memory_format=torch.channels_last)
+    x.requires_grad_(True)
+    n0 = _launches()
+    out = m(x)
+    fv = _abi.load().nfp_last_variant().decode()
+    out.backward(torch.from_numpy(goh).to(dev).to(dtype))
+    torch.cuda.synchronize()
+    bv = _abi.load().nfp_last_variant().decode()
+    assert _launches() == n0 + 2, (fv, bv)                        # ONE forward and ONE backward kernel
+    assert fv.startswith("fwd_band<R1+2,") and bv.startswith("bwd_fast<R1+2,"), (fv, bv)
+    c1 = dict(R=1, measure=measure, padding=1, padding_mode=mode, **({"p": 2} if measure == "norm" else {}))
+    c2 = dict(c1, R=2, padding=2)
+    ref_out = np.concatenate([oracle_lib.forward(xh, **c1), oracle_lib.forward(xh, **c2)], axis=1)
+    ref_gx = oracle_lib.backward(xh, goh[:, :8].copy(), **c1) + oracle_lib.backward(xh, goh[:, 8:].copy(), **c2)
+    to, tg = (1e-2, 2e-2) if bf else (TOL, TOL)
+    assert out.shape == ref_out.shape
+    assert rel_err(out.detach().float().cpu().numpy(), ref_out) <= to
+    assert rel_err(x.grad.float().cpu().numpy(), ref_gx) <= tg
+    # and bitwise equal to the two single-radius maps where those run on the same kernels (float32)
+    if not bf:
+        sep = torch.cat([blk(x.detach()) for blk in m.nfp_blocks], dim=1)
+        assert (out.detach() - sep).abs().max().item() <= 2e-6
+
+
+def test_multi_radius_falls_back_to_two_passes(dev):
+    """Radii other than (1, 2) or a measure without a fused kernel: the same concatenation from one kernel pair per
+    radius — still HIP kernels, never a CPU path.  (Replicate padding is fused while the link tables hold its folds:
+    nfp_workspace_bytes checks the exact bound per geometry.)"""
+    from neighbour_feature_pooling_amd import MultiRadiusNFPPooling, _abi
+    x = torch.randn(2, 16, 9, 9, device=dev)
+    for kw, fused in ((dict(R_list=(1, 2), measure="cosine", padding_mode="replicate"), None),
+                      (dict(R_list=(1, 2), measure="dot"), False), (dict(R_list=(2, 3), measure="cosine"), False)):
+        m = MultiRadiusNFPPooling(16, **kw)
+        n0 = _launches()
+        y = m(x)
+        n = _launches() - n0
+        assert n >= (2 if fused is False else 1)
+        ref = torch.cat([b(x) for b in m.nfp_blocks], dim=1)
+        assert (y - ref).abs().max().item() <= 2e-6

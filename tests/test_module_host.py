@@ -139,3 +139,20 @@ def test_plan_cache_is_lru():
     assert len(F._PLANS) == F._PLANS_MAX
     assert F._plans_get(("k", 0)) == 0 and F._plans_get(("k", 1)) is None
     F._PLANS.clear()
+
+
+def test_multi_radius_module_on_cpu_is_the_concatenation():
+    """MultiRadiusNFPPooling = torch.cat of one NFP layer per radius (nfp_heads.py:88-93,109-110)."""
+    from neighbour_feature_pooling_amd import MultiRadiusNFPPooling
+    m = MultiRadiusNFPPooling(16, R_list=(1, 2), measure="cosine")
+    assert m.out_channels == 8 + 24 and len(m.nfp_blocks) == 2
+    x = torch.randn(2, 16, 7, 7, requires_grad=True)
+    y = m(x)
+    ref = torch.cat([NFPPooling(16, R=1, measure="cosine", padding=1)(x), NFPPooling(16, R=2, measure="cosine", padding=2)(x)], 1)
+    assert y.shape == (2, 32, 7, 7) and torch.equal(y, ref)
+    y.sum().backward()
+    assert x.grad is not None
+    with torch.no_grad():   # the reference heads probe their NFP blocks with a CPU dummy in __init__ (nfp_heads.py:94-97)
+        assert sum(b(torch.randn(1, 16, 7, 7)).shape[1] for b in m.nfp_blocks) == 32
+    m3 = MultiRadiusNFPPooling(8, R_list=(1, 2, 3), measure="norm", p=2)
+    assert m3(torch.randn(1, 8, 9, 9)).shape == (1, 8 + 24 + 48, 9, 9)
