@@ -44,7 +44,7 @@ import bench
 sys.argv = ["bench.py"] + sys.argv[1:]
 key = bench.workload_key(bench.parse())
 one = json.load(open("gpurun_out/traffic.json"))
-path = "profiles/traffic_latest.json"
+path = "gpurun_out/traffic_workloads.json" if os.path.exists("gpurun_out/traffic_workloads.json") else "profiles/traffic_latest.json"
 allw = json.load(open(path)) if os.path.exists(path) else {"note": one["note"]}
 if allw.get("source_hash") != bench.source_hash():   # profiles of other kernel sources are stale: start over
     allw = {"note": one["note"], "source_hash": bench.source_hash()}
