@@ -56,8 +56,14 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 using Rsrc = __amdgpu_buffer_rsrc_t;
 constexpr int kAuxSc1 = 16;  // buffer-store cache policy: sc1 = write-through
+// grad_x store policy (A/B knob, scripts/ab_flags.py).  Plain write-back stores: the 196-byte NCHW rows a workgroup
+// writes are adjacent in memory, and only the L2 can merge them into whole sectors — as write-through (sc1) dwords
+// they left as partial sectors, 1.25x the bytes (WRITE_SIZE 8.03 MB for 6.42 MB of grad_x).  Round 1 measured sc1
+// 0.45 us FASTER at the headline shape, on a buffer it rewrote in place (Infinity-Cache resident); writing a fresh
+// grad_x per step, as training does, plain stores are faster at every batch: 6.2 vs 6.9 us at B = 64, 162 vs 266 us
+// at B = 4096 (profiles/r02_i_store_policy_ab.txt).
 #ifndef NFP_BWD_STORE_AUX
-#define NFP_BWD_STORE_AUX kAuxSc1  // A/B knob (scripts/ab_flags.py)
+#define NFP_BWD_STORE_AUX 0
 #endif
 __device__ __forceinline__ Rsrc make_rsrc(const void* base, long long bytes) {
   return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)(bytes > 0x7ffffff0LL ? 0x7ffffff0LL : bytes), 0x00020000);
@@ -613,10 +619,9 @@ __global__ void __launch_bounds__(GEMM ? 1024 : kBwdThreads) bwd_fast(const KP g
     }
     if constexpr (!FOLD_PHASE) w[K2 / 2] = fmaf(M == NFP_COSINE ? dfn[active ? p : 0] : 1.f, dsum, w[K2 / 2]);
   }
-  // B: one pass over the channel block; results leave straight from registers with write-through
-  // (sc1) stores — 4 dwords per slot for NCHW, one 16-byte store for channels-last — so grad_x
-  // streams out of L2 during the kernel instead of in its end-of-kernel flush (measured -0.45 us;
-  // an LDS-transposed 16-byte NCHW epilogue was 1.6 us slower).
+  // B: one pass over the channel block; results leave straight from registers — 4 dwords per slot for NCHW, one
+  // 16-byte store for channels-last (store policy: NFP_BWD_STORE_AUX above; an LDS-transposed 16-byte NCHW epilogue
+  // was 1.6 us slower).
   const int Pp = (P + 3) & ~3, sp = swz(p);
   for (int c0 = cb0; c0 < cb1; c0 += g.Cc) {
     const int ncq = min(g.Cc, cb1 - c0) >> 2;
