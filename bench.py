@@ -9,13 +9,14 @@ Workload at every N: BASELINE.json configs[1], NFP(cosine, k=3) on [B=64, C=512,
 scaling: every rank owns its own batch; the path has no exchange step, so there is no collective in the
 timed region beyond the bracketing barriers).  Prints ONE JSON line on rank 0.
 
-Two legs:
-  * `value` / `ms_per_step` / `roofline`: the ROTATING leg — step i works on buffer set i mod S, S sets of
-    (x, grad_out) holding more than 256 MiB of x alone, so that no step finds its input in the 256 MiB
-    Infinity Cache: x, grad_out and grad_x are HBM traffic (within a step the backward re-reads the x its
-    forward read microseconds before).  This is the figure the HBM roofline fraction is quoted on.
-  * `cache_resident`: the same K steps on ONE buffer set (6.4 MB of x: served by L2 / Infinity Cache after the
-    first step) — what a training step sees when the backbone has just written the feature map.
+Two legs, both timed over exactly K steps between barriers:
+  * `value` / `ms_per_step`: K steps on ONE set of (x, grad_out) — 6.4 MB of x, served by L2 / the 256 MiB Infinity
+    Cache after the first step, which is what a training step sees: the backbone has just written the feature map.
+    (Round 1's protocol; every step still writes a fresh out / grad_x buffer.)
+  * `cold` and `roofline`: the ROTATING leg — step i works on buffer set i mod S, S sets holding more than 256 MiB
+    of x alone, a fresh grad_x / out per step, and a 512 MiB fill right before the clock starts: x, grad_out and
+    grad_x are HBM traffic (within a step the backward re-reads the x its forward read microseconds before).  The
+    HBM roofline fraction is quoted on THIS leg's kernel times, never on the cache-resident ones.
 The K timed steps are captured once into a HIP graph and replayed (`--launch eager` times plain launches
 instead): a step is ~11 us of GPU work, far below the host cost of two Python->ctypes->hipLaunch round trips.
 """
@@ -412,8 +413,12 @@ def main():
 
     stream = torch.cuda.Stream(device=dev)
 
-    def timed(w):
-        """K steps of workload `w` on `stream`: (elapsed seconds, launches counted by the library)."""
+    flush_buf = torch.empty(2 * INFINITY_CACHE_BYTES, dtype=torch.uint8, device=dev)
+
+    def timed(w, cold=True):
+        """K steps of workload `w` on `stream`: elapsed seconds.  cold: a 512 MiB fill runs (untimed) right before the
+        timed region, so that nothing the steps read or write — x, grad_out, and the grad_x / out buffers the graph
+        wrote on its previous replay — is still in the 256 MiB Infinity Cache when the clock starts."""
         with torch.cuda.stream(stream):
             for i in range(args.warmup):
                 w.step(i)
@@ -427,6 +432,8 @@ def main():
             n_graph = L.nfp_launch_count() - n0
             torch.cuda.synchronize()
             graph.replay()  # untimed: first replay uploads the graph
+            if cold:
+                flush_buf.fill_(1)
             torch.cuda.synchronize()
             barrier()
             torch.cuda.synchronize()
@@ -437,6 +444,8 @@ def main():
             t1 = time.perf_counter()
             del graph
         else:
+            if cold:
+                flush_buf.fill_(1)
             barrier()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -452,9 +461,9 @@ def main():
 
     from neighbour_feature_pooling_amd.parallel import max_over_ranks
     red_dev = dev if backend == "nccl" else "cpu"
-    elapsed = max_over_ranks(timed(rot), device=red_dev)
+    elapsed_cold = max_over_ranks(timed(rot), device=red_dev)
+    elapsed = max_over_ranks(timed(hot, cold=False), device=red_dev)
     extras = world == 1 and not args.no_extras
-    elapsed_hot = timed(hot) if extras else None
     with torch.cuda.stream(stream):
         out = hot.m(hot.x[0])
         fwd_variant = L.nfp_last_variant().decode()
@@ -496,18 +505,24 @@ def main():
             "config": {"workload": f"NFP({args.measure},k={2 * R + 1},reflect pad {R}) fwd+bwd on "
                                    f"[{B},{C},{S},{S}] {args.dtype} {args.layout.upper()} per GPU (BASELINE.json configs[1])",
                        "batch_per_gpu": B, "global_batch": B * world, "launch": args.launch,
-                       "buffers": f"rotating: {rot.sets} sets of (x, grad_out), {rot.sets * rot.B * C * S * S * e >> 20} MiB of x "
-                                  f"per GPU (> 256 MiB Infinity Cache): every step reads its input from HBM",
+                       "buffers": "value / ms_per_step: one resident set of (x, grad_out) per GPU, a fresh out / grad_x buffer per "
+                                  "step (round 1's protocol: the feature map has just been written by the backbone); "
+                                  "`cold` and `roofline`: rotating sets, every byte from HBM",
                        "parallelism": f"batch-sharded replicas x{world}, no data-path collective"},
-            "roofline": {"bound": "hbm", "leg": "rotating buffers, kernel timed inside the step sequence (grad_out, out and "
-                                                  "grad_x are HBM traffic; the backward re-reads the x its forward read "
+            "cold": {"what": f"the same K steps over {rot.sets} rotating sets of (x, grad_out) = "
+                             f"{rot.sets * rot.B * C * S * S * e >> 20} MiB of x per GPU (> 256 MiB Infinity Cache), a fresh "
+                             f"grad_x / out per step, 512 MiB fill right before the clock: every step reads and writes HBM",
+                     "value": round(world * px_per_step * args.steps / elapsed_cold / 1e6, 3), "unit": "Mpixels/s",
+                     "ms_per_step": round(elapsed_cold / args.steps * 1e3, 6)},
+            "roofline": {"bound": "hbm", "leg": "cold: rotating buffers, kernel timed inside the step sequence (grad_out, out "
+                                                  "and grad_x are HBM traffic; the backward re-reads the x its forward read "
                                                   "microseconds earlier)",
                          "kernel": f"{dom}:{dom_variant}",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_us": round(dom_t, 3)},
-            "kernels": {"how": "forward_us: HIP events around a graph of rotating forwards / launches; backward_us: the same "
+            "kernels": {"leg": "cold (rotating buffers)", "how": "forward_us: HIP events around a graph of rotating forwards / launches; backward_us: the same "
                                "around a graph of rotating steps, minus forward_us (launch boundaries included, as in "
                                "the timed region and in rocprofv3's trace of a graph replay); *_eager_event_us: mean / "
                                "median of each launch's own hipExtLaunchKernel event pair, eager order, idle GPU between",
@@ -520,9 +535,7 @@ def main():
         }
         if extras:
             tf_hot, tb_hot = hot.kernel_times(stream, reps=50)
-            res["cache_resident"] = {"what": "the same K steps on ONE buffer set (inputs served by L2 / Infinity Cache)",
-                                     "value": round(px_per_step * args.steps / elapsed_hot / 1e6, 3),
-                                     "ms_per_step": round(elapsed_hot / args.steps * 1e3, 6),
+            res["cache_resident"] = {"what": "kernel times of the `value` leg (one buffer set: inputs from L2 / Infinity Cache)",
                                      "forward_us": round(tf_hot, 3), "backward_us": round(tb_hot, 3),
                                      "fwd_GBs": round(rot.fb / tf_hot / 1e3, 1), "bwd_GBs": round(rot.bb / tb_hot / 1e3, 1)}
             rl = Workload(args, dev, rank, relu=True)                       # what a ResNet trunk emits: x >= 0, ~50 % zeros
