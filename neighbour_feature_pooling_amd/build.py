@@ -38,5 +38,37 @@ def build_hip(force=False, verbose=False):
     return LIB
 
 
+TORCH_EXT = os.path.join(_HERE, "_nfp_torch.so")
+
+
+def build_torch_ext(force=False, verbose=False):
+    """Compile csrc/nfp_torch.cpp (C++ autograd nodes over the C ABI; host code only) -> _nfp_torch.so next to
+    libnfp_hip.so, with g++ against libtorch.  Returns the module path."""
+    import sysconfig
+    import torch
+    from torch.utils import cpp_extension as ce
+    src = os.path.join(CSRC, "nfp_torch.cpp")
+    newest = max(os.path.getmtime(src), os.path.getmtime(os.path.join(_HERE, "..", "include", "nfp.h")))
+    if not force and os.path.exists(TORCH_EXT) and os.path.getmtime(TORCH_EXT) >= newest:
+        return TORCH_EXT
+    build_hip()
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
+           "-DTORCH_EXTENSION_NAME=_nfp_torch", "-DTORCH_API_INCLUDE_EXTENSION_H",
+           f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}", "-Wno-deprecated-declarations"]
+    cmd += [f"-I{p}" for p in ce.include_paths()] + [f"-I{rocm}/include", f"-I{sysconfig.get_paths()['include']}"]
+    cmd += [src, "-o", TORCH_EXT + ".tmp"]
+    for lp in ce.library_paths():
+        cmd += [f"-L{lp}", f"-Wl,-rpath,{lp}"]
+    cmd += ["-lc10", "-lc10_hip", "-ltorch_cpu", "-ltorch", "-ltorch_hip", "-ltorch_python",
+            f"-L{_HERE}", "-lnfp_hip", "-Wl,-rpath,$ORIGIN"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    os.replace(TORCH_EXT + ".tmp", TORCH_EXT)
+    return TORCH_EXT
+
+
 if __name__ == "__main__":
     print(build_hip(force=True, verbose=True))
+    print(build_torch_ext(force=True, verbose=True))

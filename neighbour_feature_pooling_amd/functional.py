@@ -43,6 +43,43 @@ class NfpConfig:
 
 _DTYPES = {torch.float32: _abi.F32, torch.bfloat16: _abi.BF16}
 
+_CPP = None     # the C++ autograd nodes (csrc/nfp_torch.cpp), None until looked for, False when absent
+
+
+def _cpp_nodes():
+    """neighbour_feature_pooling_amd/_nfp_torch.so — the same two autograd nodes as the Python classes below, in C++
+    (no interpreter on the launch path).  Optional: NFP_PY_NODES=1 or a missing module selects the Python nodes."""
+    global _CPP
+    if _CPP is None:
+        import importlib.util
+        import os
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_nfp_torch.so")
+        _CPP = False
+        if os.environ.get("NFP_PY_NODES") != "1" and os.path.exists(path):
+            _abi.load()     # libnfp_hip.so first: the module links against it
+            spec = importlib.util.spec_from_file_location(__package__ + "._nfp_torch", path)
+            mod = importlib.util.module_from_spec(spec)
+            try:
+                spec.loader.exec_module(mod)
+                if mod.desc_bytes == ctypes.sizeof(_abi.NfpDesc):
+                    _CPP = mod
+            except (ImportError, OSError):   # built against another torch: the Python nodes serve
+                _CPP = False
+    return _CPP
+
+
+def _cpp_call(fn, *args):
+    """Run a C++ node; its TORCH_CHECK messages carry the library's error class as a prefix."""
+    try:
+        return fn(*args)
+    except RuntimeError as e:
+        msg = str(e).split("\n")[0]
+        if "libnfp_hip unsupported: " in msg:
+            raise _abi.NfpUnsupported("libnfp_hip: " + msg.split("libnfp_hip unsupported: ", 1)[1]) from None
+        if "libnfp_hip error: " in msg:
+            raise _abi.NfpError("libnfp_hip: " + msg.split("libnfp_hip error: ", 1)[1]) from None
+        raise
+
 
 def _inner_layout(x):
     """'nchw' / 'nhwc' when every image of x is dense in that order — whatever the batch stride: the kernels take the
@@ -130,6 +167,7 @@ def _workspace(d, device):
     return ws.data_ptr() if ws is not False else None
 
 
+_DESC_TENSORS = {}          # id(descriptor) -> (descriptor, uint8 tensor over its bytes)
 _PLANS = OrderedDict()      # least recently used first
 _PLANS_MAX = 256
 
@@ -164,6 +202,11 @@ def _plan(x, layout, cfg):
         no_bwd = None if rc == 0 else L.nfp_last_error().decode()
         plan = (d, output_shape(d), int(L.nfp_saved_floats(ctypes.byref(d))), no_bwd)
         _plans_put(key, plan)
+        _DESC_TENSORS[id(d)] = (d, torch.frombuffer(d, dtype=torch.uint8))   # (same memory; for the C++ nodes)
+        if len(_DESC_TENSORS) > 4 * _PLANS_MAX:
+            live = {id(p[0]) for p in _PLANS.values() if isinstance(p, tuple)}
+            for k in [k for k in _DESC_TENSORS if k not in live]:
+                del _DESC_TENSORS[k]
     return plan
 
 
@@ -296,6 +339,13 @@ def nfp_pool(x, cfg):
     """(GAP(x) [B,C], GAP(NFP(x)) [B,N]) — NFP_Pooling.py:27-31.  Fused on the GPU where supported,
     otherwise the same two reductions composed from `nfp` and torch ops."""
     if x.dim() == 4 and nfp_pool_fused_ok(x, cfg):
+        cpp = _cpp_nodes()
+        if cpp:
+            xd, layout = _dense(x)
+            d, oshape, ns, _ = _plan(xd, layout, cfg)
+            gap, nfpm = _cpp_call(cpp.nfp_pool_apply, xd, _DESC_TENSORS[id(d)][1], list(oshape), max(ns, 0),
+                                  layout == "nhwc")
+            return gap, nfpm
         return _NfpPoolHip.apply(x, cfg)
     return x.mean((2, 3)), nfp(x, cfg).mean((2, 3))
 
@@ -331,7 +381,18 @@ def nfp(x, cfg):
                       "PyTorch ops on the GPU, not through the HIP kernels", RuntimeWarning, stacklevel=3)
         return nfp_host(x, cfg)
     if x.is_cuda:
-        return _NfpHip.apply(x, cfg, x.requires_grad and torch.is_grad_enabled())
+        need_grad = x.requires_grad and torch.is_grad_enabled()
+        cpp = _cpp_nodes()
+        if cpp:
+            xd, layout = _dense(x)
+            d, oshape, ns, no_bwd = _plan(xd, layout, cfg)
+            if need_grad and no_bwd is not None:
+                raise _abi.NfpUnsupported(f"libnfp_hip: the forward of this call is served but its backward is not "
+                                          f"({no_bwd}); run it under torch.no_grad() or on a detached input")
+            if not need_grad and not (cfg.measure == "attention" and x.dtype != torch.float32):
+                ns = 0
+            return _cpp_call(cpp.nfp_apply, xd, _DESC_TENSORS[id(d)][1], list(oshape), max(ns, 0), layout == "nhwc")
+        return _NfpHip.apply(x, cfg, need_grad)
     if cfg.inner_R:
         import dataclasses
         return torch.cat([nfp_host(x, dataclasses.replace(cfg, R=cfg.inner_R, padding=cfg.inner_R, inner_R=0)),

@@ -181,3 +181,15 @@ def test_workspace_bytes(lib):
     assert a == lib.nfp_workspace_bytes(ctypes.byref(_desc((64, 512, 7, 7), measure="norm")))
     d = _desc((64, 512, 7, 7))
     assert lib.nfp_workspace_init(ctypes.byref(d), None, None) == -1
+
+
+def test_cpp_autograd_module_builds_and_matches_the_descriptor(lib):
+    """csrc/nfp_torch.cpp (C++ autograd nodes over the C ABI) builds against this torch, loads, exposes its two nodes
+    and agrees with the ctypes binding on sizeof(nfp_desc); no compute without a GPU."""
+    from neighbour_feature_pooling_amd import functional
+    from neighbour_feature_pooling_amd.build import build_torch_ext
+    build_torch_ext()
+    functional._CPP = None
+    cpp = functional._cpp_nodes()
+    assert cpp and cpp.desc_bytes == ctypes.sizeof(_abi.NfpDesc)
+    assert callable(cpp.nfp_apply) and callable(cpp.nfp_pool_apply)

@@ -1069,3 +1069,50 @@ def test_multi_radius_falls_back_to_two_passes(dev):
         assert n >= (2 if fused is False else 1)
         ref = torch.cat([b(x) for b in m.nfp_blocks], dim=1)
         assert (y - ref).abs().max().item() <= 2e-6
+
+
+# ---- C++ autograd nodes (csrc/nfp_torch.cpp) vs the Python nodes of functional.py ----------------------------------
+
+def test_cpp_autograd_nodes_equal_python_nodes(dev):
+    """Both node flavours drive the same C ABI: identical outputs and gradients, same launches, same error classes."""
+    from neighbour_feature_pooling_amd import NFPPooling, _abi, functional
+    from neighbour_feature_pooling_amd.functional import nfp_pool
+    cpp = functional._cpp_nodes()
+    assert cpp, "the C++ autograd nodes (_nfp_torch.so) are not built / do not load"
+    cases = [((8, 64, 7, 7), dict(R=1, measure="cosine", padding=1), torch.float32, False),
+             ((4, 192, 14, 14), dict(R=2, measure="norm", p=2, padding=2), torch.bfloat16, True),
+             ((2, 12, 9, 8), dict(R=1, measure="canberra", padding=2, stride=2), torch.float32, False),
+             ((3, 16, 6, 6), dict(R=1, measure="attention", padding=1), torch.bfloat16, False)]
+    for shape, ctor, dtype, nhwc in cases:
+        m = NFPPooling(shape[1], **ctor)
+        x0 = (torch.rand(shape, device=dev) + 0.25).to(dtype)
+        if nhwc:
+            x0 = x0.contiguous(memory_format=torch.channels_last)
+        res = []
+        for flavour in (cpp, False):
+            functional._CPP = flavour
+            try:
+                x = x0.clone(memory_format=torch.preserve_format).requires_grad_(True)
+                n0 = _launches()
+                out = m(x)
+                go = torch.ones_like(out) * 0.5
+                gx, = torch.autograd.grad(out, x, go)
+                torch.cuda.synchronize()
+                res.append((out.detach(), gx, _launches() - n0))
+                if ctor["measure"] in ("cosine", "norm") and ctor.get("stride", 1) == 1:
+                    x = x0.clone(memory_format=torch.preserve_format).requires_grad_(True)
+                    gap, nfpm = nfp_pool(x, m.config)
+                    (gap.sum() + 2.0 * nfpm.sum()).backward()
+                    res[-1] += (gap.detach(), nfpm.detach(), x.grad)
+                    x = x0.clone(memory_format=torch.preserve_format).requires_grad_(True)
+                    gap, nfpm = nfp_pool(x, m.config)
+                    nfpm.sum().backward()                       # gap unused: its gradient arrives undefined
+                    res[-1] += (x.grad,)
+            finally:
+                functional._CPP = cpp
+        a, b = res
+        assert a[2] == b[2]
+        for u, v in zip(a[:2] + a[3:], b[:2] + b[3:]):
+            assert torch.equal(u, v)
+    with pytest.raises(_abi.NfpUnsupported, match="norm order"):
+        NFPPooling(8, padding=1, measure="norm", p=float("inf"))(torch.randn(1, 8, 5, 5, device=dev))
