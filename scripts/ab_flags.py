@@ -43,7 +43,8 @@ def build_all(variants):
 
 
 CODE = """
-import sys; sys.path.insert(0, {root!r})
+import os, sys; sys.path.insert(0, {root!r})
+os.environ["NFP_PY_NODES"] = "1"   # (the C++ nodes link the product library; the Python nodes call whatever _abi loads)
 import torch
 from neighbour_feature_pooling_amd import _abi
 _abi.LIB_PATH = {lib!r}

@@ -4,6 +4,7 @@ per kernel, the median workgroup's time between phase stamps.  Read SHARES, not 
     python scripts/diag_stamps.py [B C S R measure]
 """
 import ctypes, os, subprocess, sys
+os.environ["NFP_PY_NODES"] = "1"   # the C++ autograd nodes link the product library; the diagnostic one is loaded by ctypes
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
