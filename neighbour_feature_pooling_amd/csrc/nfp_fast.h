@@ -625,14 +625,13 @@ __global__ void __launch_bounds__(GEMM ? 1024 : kBwdThreads) bwd_fast(const KP g
   const int Pp = (P + 3) & ~3, sp = swz(p);
   for (int c0 = cb0; c0 < cb1; c0 += g.Cc) {
     const int ncq = min(g.Cc, cb1 - c0) >> 2;
-    if (c0 > cb0) {
-      __syncthreads();
-      x_issue(c0, ncq);
-    }
+    if (c0 > cb0) __syncthreads();  // previous chunk fully consumed
     if (c0 > cb0 || !g.early) {
       x_commit(ncq);
       __syncthreads();
     }
+    // the next chunk's loads fly while this one is processed (the staging registers are free once committed)
+    if (c0 + g.Cc < cb1) x_issue(c0 + g.Cc, min(g.Cc, cb1 - c0 - g.Cc) >> 2);
     NFP_STAMP(5);
     if (active) {
 #pragma unroll NFP_UNROLL_B
