@@ -11,7 +11,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB = os.path.join(_HERE, "libnfp_hip.so")
 SOURCES = ["nfp_hip.hip"]
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+# -fno-slp-vectorize: left to itself hipcc packs adjacent scalar f32 FMAs of the channel loops into v_pk_fma_f32,
+# which costs more issue time than it saves at two wavefronts per SIMD (headline forward 5.31 -> 5.10 us,
+# [256,512,7,7] forward 7.8 -> 7.5 us; scripts/ab_flags.py)
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-slp-vectorize",
                "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 
 

@@ -642,9 +642,6 @@ __global__ void __launch_bounds__(GEMM ? 1024 : kBwdThreads) bwd_fast(const KP g
           const float4 gg = *(const float4*)(ggap + (long long)b * g.C + c0 + 4 * cq);
           r4 = make_float4(gg.x * g.invP, gg.y * g.invP, gg.z * g.invP, gg.w * g.invP);
         }
-#ifdef NFP_EXP_NOCOMPUTE
-        r4 = make_float4(w[0] + cq, w[1], w[2], w[3]);
-#else
 #pragma unroll
         for (int j = 0; j < K2; ++j) {
           const float4 q = row[off[j]];
@@ -653,10 +650,6 @@ __global__ void __launch_bounds__(GEMM ? 1024 : kBwdThreads) bwd_fast(const KP g
           r4.z = fmaf(w[j], q.z, r4.z);
           r4.w = fmaf(w[j], q.w, r4.w);
         }
-#endif
-#ifdef NFP_EXP_NOSTORE
-        if (r4.x == 1234.5f)
-#endif
         if constexpr (NHWC) {
           store_px4<BF>(gxb, p * g.C + c0 + 4 * cq, 0, r4);
         } else {
