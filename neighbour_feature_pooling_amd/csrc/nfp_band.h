@@ -20,9 +20,9 @@
 namespace nfp {
 
 #ifndef NFP_BAND_T
-#define NFP_BAND_T 512
+#define NFP_BAND_T 1024
 #endif
-constexpr int kBandT = NFP_BAND_T;  // threads per workgroup
+constexpr int kBandT = NFP_BAND_T;  // most threads per workgroup: pixels of the band x channel groups (a power of two <= 32)
 constexpr int kBandRB = 3;   // NCHW staging: 4-pixel x 4-channel blocks per thread per chunk
 constexpr int kBandRN = 6;   // channels-last staging: slots per thread per chunk
 
@@ -37,33 +37,54 @@ struct FoffQ {
 // same pass emits  gap[b,c] = mean over pixels of x[b,c]  (AdaptiveAvgPool2d(1), NFP_Pooling.py:27) and
 // nfpm[b,n] = mean over pixels of out[b,n]  (adaptive_avg_pool2d of the NFP maps, NFP_Pooling.py:31), both float32,
 // summed in a fixed order, for either layout and storage type (the sums are taken from the float32 LDS slab).
+//
+// Thread maps.  Channel sums: thread t = lp * G + gl — the G channel groups of a pixel are ADJACENT LANES (G a power
+// of two <= 32, g.G; g.Tc = log2 G), so the groups' partial sums are joined by a fixed DPP tree inside the wavefront:
+// no LDS round trip, no barrier.  Outputs: thread t = gl' * Ps + lp' — lanes along pixels, coalesced stores.
+// sum over the G adjacent lanes of a group (G a power of two <= 32); valid in the group's LAST lane (in every lane of
+// the group for G <= 16).  DPP lane exchanges: no LDS round trip, a fixed order.
+#define NFP_DPP_ADD(v, ctrl, rows) \
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, rows, 0xF, false))
+__device__ __forceinline__ float group_sum(float v, int G) {
+  if (G >= 2) NFP_DPP_ADD(v, 0xB1, 0xF);    // quad_perm [1,0,3,2]: lane ^ 1
+  if (G >= 4) NFP_DPP_ADD(v, 0x4E, 0xF);    // quad_perm [2,3,0,1]: lane ^ 2
+  if (G >= 8) NFP_DPP_ADD(v, 0x141, 0xF);   // row_half_mirror: the other quad of each 8 lanes
+  if (G >= 16) NFP_DPP_ADD(v, 0x140, 0xF);  // row_mirror: the other half of each row of 16
+  if (G >= 32) NFP_DPP_ADD(v, 0x142, 0xA);  // row_bcast15 into rows 1 and 3: the row before
+  return v;
+}
+#undef NFP_DPP_ADD
+
 template <int R, int M, bool BF, bool NHWC, bool POOL = false>
-__global__ void __launch_bounds__(kBandT) fwd_band(const KP g, const void* __restrict__ x, void* __restrict__ out,
-                                                   float* __restrict__ saved, const unsigned char* __restrict__ ws,
-                                                   int rb, float* __restrict__ gap, float* __restrict__ nfpm) {
+__global__ void __launch_bounds__(1024) fwd_band(const KP g, const void* __restrict__ x, void* __restrict__ out,
+                                                 float* __restrict__ saved, const unsigned char* __restrict__ ws,
+                                                 int rb, float* __restrict__ gap, float* __restrict__ nfpm) {
   constexpr int N = Win<R>::N, NF = Win<R>::NF;
   constexpr int ES = BF ? 2 : 4;
   extern __shared__ __attribute__((aligned(16))) float4 lds4[];
   float4* slab = lds4;
   const int P = g.P, W = g.W;
-  const int b = blockIdx.x, band = blockIdx.y, t = threadIdx.x;
-  constexpr int T = kBandT;
+  const int b = blockIdx.x, band = blockIdx.y, t = threadIdx.x, T = blockDim.x;
   // rows: owned [y0, y1), staged [y0, ye); pixels: owned [p0, po), staged [p0, pe)
   const int y0 = band * rb, y1 = min(g.H, y0 + rb), ye = min(g.H, y1 + g.R);
   const int p0 = y0 * W, po = y1 * W, pe = ye * W, Ps = pe - p0;
-  const int base = p0 & ~7;                      // slot origin of the band's slab rows
-  const int Ppb = ((pe + 3) & ~3) - base;        // slots per slab row (one channel quad)
-  const int G = min(fdivi(T, Ps), g.C >> 2);     // channel groups: thread (lp, gl) owns quads gl, gl + G, ...
-  const int gl = fdivi(t, Ps), lp = t - gl * Ps, p = p0 + lp;
-  const bool active = gl < G;
+  const int base = p0 & ~7;                          // slot origin of the band's slab rows
+  const int Ppb = (((pe + 3) & ~3) - base) | 1;      // slots per slab row (one channel quad); odd: the G adjacent lanes
+                                                     // of a pixel read G different rows at one slot — distinct banks
+  const int G = g.G, lg = g.Tc;                      // channel groups (power of two), log2
+  const int gl = t & (G - 1), lpc = t >> lg;         // channel-sum map
+  const bool active = lpc < Ps;
+  const int lp = min(lpc, Ps - 1), p = p0 + lp;
+  const int glf = fdivi(t, Ps), lpf = t - glf * Ps, pf = p0 + lpf;   // output map
   const Rsrc xb = make_rsrc((const char*)x + (long long)b * g.sB * ES, (long long)g.C * P * ES);  // wave-uniform
   const WsLayout L = ws_layout(P, R, g.mode);
+  float* Tt = (float*)(lds4 + (g.Cc >> 2) * Ppb);    // [NF+1][Ps] behind the slab: pair sums per direction, then |x|^2
 
   NFP_STAMP_INIT();
   NFP_STAMP(0);
   // ---- tables first (small, shared by every workgroup: L2), then the x chunk ---------------------------------
   const uint32_t* ftt = (const uint32_t*)(ws + L.ft);
-  uint32_t fte = ftt[min(gl, N - 1) * P + p];     // this thread's first output (n = gl, p)
+  uint32_t fte = ftt[min(glf, N - 1) * P + pf];   // this thread's first output (n = glf, pf)
   uint4 fo[FoffQ<R>::v];
   {
     const uint4* fot = (const uint4*)(ws + L.foff) + (long long)p * FoffQ<R>::v;
@@ -79,11 +100,10 @@ __global__ void __launch_bounds__(kBandT) fwd_band(const KP g, const void* __res
   float4 nv[kBandRN];
   auto issue = [&](int c0, int ncq) {
     if constexpr (NHWC) {
-      const int g0 = active ? gl : 0;
-      const int last = g0 < ncq ? g0 + fdivi(ncq - 1 - g0, G) * G : 0;
+      const int last = gl < ncq ? gl + (((ncq - 1 - gl) >> lg) << lg) : 0;
 #pragma unroll
       for (int k = 0; k < kBandRN; ++k) {
-        const int cq = min(g0 + k * G, last);
+        const int cq = min(gl + k * G, last);
         nv[k] = load_px4<BF>(xb, p * g.C + c0 + 4 * cq, 0);
       }
     } else {
@@ -160,15 +180,10 @@ __global__ void __launch_bounds__(kBandT) fwd_band(const KP g, const void* __res
           s4.z += v.z;
           s4.w += v.w;
         }
-        auto join = [](float v) {
-          v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false));
-          v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, false));
-          return v;
-        };
-        s4.x = join(s4.x);
-        s4.y = join(s4.y);
-        s4.z = join(s4.z);
-        s4.w = join(s4.w);
+        s4.x = group_sum(s4.x, 4);
+        s4.y = group_sum(s4.y, 4);
+        s4.z = group_sum(s4.z, 4);
+        s4.w = group_sum(s4.w, 4);
         if (i < ncq * 4 && part == 0)
           *(float4*)(gap + (long long)b * g.C + c0 + 4 * cq) =
               make_float4(s4.x * g.invP, s4.y * g.invP, s4.z * g.invP, s4.w * g.invP);
@@ -192,50 +207,30 @@ __global__ void __launch_bounds__(kBandT) fwd_band(const KP g, const void* __res
       }
     }
   }
-  // ---- channel-group reduction through LDS, fixed order -------------------------------------------------------
-  __syncthreads();
+  // ---- channel groups joined inside the wavefront (fixed tree), one lane per pixel publishes the sums ---------
   NFP_STAMP(3);
-  float* red = (float*)lds4;              // [G][NF+1][Ps]
   const int NV = (NF + 1) * Ps;
-  float* Tt = red + G * NV;               // [NF+1][Ps]: pair sums per forward direction, then |x|^2
-  if (active) {
 #pragma unroll
-    for (int d = 0; d < NF; ++d) red[gl * NV + d * Ps + lp] = acc[d];
-    red[gl * NV + NF * Ps + lp] = nrm;
-  }
-  __syncthreads();
-  // value i is summed by S adjacent lanes (S = 1, 2 or 4: as many as the workgroup has to spare), lane `part` taking
-  // groups part, part + S, ...; the partial sums are joined by a fixed xor tree, so the order never varies
-  const int S = NV * 4 <= T ? 4 : (NV * 2 <= T ? 2 : 1), sh = S == 4 ? 2 : (S == 2 ? 1 : 0);
-  for (int i0 = 0; i0 < NV; i0 += T >> sh) {
-    const int i = i0 + (t >> sh), part = t & (S - 1);
-    float s = 0.f;
-    const float* col = red + min(i, NV - 1);
-    for (int gg = part; gg < G; gg += 4 * S) {  // four reads in flight, added in a fixed order
-      const float v0 = col[gg * NV];
-      const float v1 = gg + S < G ? col[(gg + S) * NV] : 0.f;
-      const float v2 = gg + 2 * S < G ? col[(gg + 2 * S) * NV] : 0.f;
-      const float v3 = gg + 3 * S < G ? col[(gg + 3 * S) * NV] : 0.f;
-      s += (v0 + v1) + (v2 + v3);
-    }
-    // quad_perm lane exchanges (DPP: no LDS round trip): lane ^ 1, then lane ^ 2
-    if (S >= 2) s += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s), 0xB1, 0xF, 0xF, false));
-    if (S >= 4) s += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s), 0x4E, 0xF, 0xF, false));
-    if (i < NV && part == 0) Tt[i] = s;
+  for (int d = 0; d < NF; ++d) acc[d] = group_sum(acc[d], G);
+  nrm = group_sum(nrm, G);
+  if (active && gl == G - 1) {
+#pragma unroll
+    for (int d = 0; d < NF; ++d) Tt[d * Ps + lp] = acc[d];
+    Tt[NF * Ps + lp] = nrm;
   }
   __syncthreads();
   NFP_STAMP(4);
-  // ---- outputs (n, p) whose pair this band summed: thread (lp, n = gl, gl + G', ...) -------------------------
+  // ---- outputs (n, p) whose pair this band summed: thread (lp', n = gl', gl' + Gn, ...) ------------------------
   const float* n2 = Tt + NF * Ps;
-  const int Gn = fdivi(T, Ps);            // (all thread groups take part, not only the G that had channels)
-  if (gl < Gn) {
+  const int Gn = fdivi(T, Ps);
+  if (glf < Gn) {
     void* ob = (char*)out + (long long)b * N * P * ES;
-    const float n2p = n2[lp];
+    const float n2p = n2[lpf];
     const float ip = inv_norm(n2p, g.inv_eps);
-    for (int n = gl; n < N; n += Gn) {
-      const uint32_t e = n == gl ? fte : ftt[n * P + p];
+    for (int n = glf; n < N; n += Gn) {
+      const uint32_t e = n == glf ? fte : ftt[n * P + pf];
       const int kind = (int)(e >> 22), pix = (int)((e >> 9) & 511u), fi = (int)((e >> 18) & 15u);
-      const int q = kind == 2 ? p : (int)(e & 511u);
+      const int q = kind == 2 ? pf : (int)(e & 511u);
       if (pix >= p0 && pix < po) {
         const float pairv = Tt[fi * Ps + pix - p0];
         const float n2q = n2[q - p0];
@@ -252,11 +247,11 @@ __global__ void __launch_bounds__(kBandT) fwd_band(const KP g, const void* __res
           const float dd = __builtin_amdgcn_sqrtf(d2);
           v = g.similarity ? -dd : dd;
         }
-        stx(ob, n * P + p, v, BF ? NFP_BF16 : NFP_F32);
-        if constexpr (POOL) Tt[NV + n * Ps + lp] = v;  // vm[n][p], behind the half-stencil table
+        stx(ob, n * P + pf, v, BF ? NFP_BF16 : NFP_F32);
+        if constexpr (POOL) Tt[NV + n * Ps + lpf] = v;  // vm[n][p], behind the half-stencil table
       }
     }
-    if (M == NFP_COSINE && saved != nullptr && gl == 0 && p < po) saved[(long long)b * P + p] = __builtin_amdgcn_sqrtf(n2p);
+    if (M == NFP_COSINE && saved != nullptr && glf == 0 && pf < po) saved[(long long)b * P + pf] = __builtin_amdgcn_sqrtf(n2p);
   }
   if constexpr (POOL) {
     __syncthreads();

@@ -501,20 +501,31 @@ int launch_fwd_band_t(KP g, const void* x, void* out, float* saved, hipStream_t 
   const int rb = (g.H + nb - 1) / nb;
   nb = (g.H + rb - 1) / rb;
   const int psm = std::min(g.P, (rb + g.R) * g.W);          // most pixels a band stages
-  const int gmin = std::max(1, std::min(kBandT / psm, g.C / 4));
-  const int nqb = (psm + 3) / 4 + 1, ppb = psm + 3 + 8;     // blocks / slots per slab row, alignment slack included
-  int ncq = (NFP_FWD_SLAB_KB * 1024) / (ppb * 16);
-  ncq = std::min(ncq, NHWC ? kBandRN * gmin : (kBandRB * kBandT) / nqb);
+  // channel groups: a power of two (adjacent lanes, joined by DPP), as many as kBandT threads and C allow, <= 32
+  // (up to one workgroup per CU, latency counts: all the threads a workgroup may have; beyond, the chip is busy and
+  // every extra thread's index work is paid for: half of them)
+  const int tcap = (long long)g.B * nb > 256 ? kBandT / 2 : kBandT;
+  int lg = 0;
+  while (lg < 5 && (2 << lg) * psm <= tcap && (2 << lg) <= g.C / 4) ++lg;
+  g.G = 1 << lg;
+  g.Tc = lg;
+  const int T = ((g.G * psm + 63) / 64) * 64;
+  const int nqb = (psm + 3) / 4 + 1, ppb = (psm + 3 + 8) | 1;   // blocks / slots per slab row, alignment slack included
+  // up to one workgroup per CU the whole band is staged at once; beyond that, half-size slabs let two workgroups share a
+  // CU and overlap each other's load / sum phases ([4096,512,7,7]: 91 vs 118 us)
+  const int budget = (long long)g.B * nb > 256 ? NFP_FWD_SLAB_KB * 512 : NFP_FWD_SLAB_KB * 1024;
+  int ncq = budget / (ppb * 16);
+  ncq = std::min(ncq, NHWC ? kBandRN * g.G : (kBandRB * T) / nqb);
   if (ncq < 1) return kNotApplicable;
   const int total = g.C / 4, nch = (total + ncq - 1) / ncq;
   g.Cc = 4 * ((total + nch - 1) / nch);
   const size_t slab = (size_t)(g.Cc / 4) * ppb * 16;
-  const size_t red = (size_t)(kBandT + psm) * (NF + 1) * 4 + (POOL ? (size_t)Win<R>::N * psm * 4 : 0);
-  const size_t lds = std::max(slab, red);
+  const size_t tail = (size_t)psm * (NF + 1) * 4 + (POOL ? (size_t)Win<R>::N * psm * 4 : 0);   // Tt (+ pooled-map staging)
+  const size_t lds = slab + tail;
   if (lds > (size_t)kLdsMax) return kNotApplicable;
   snprintf(g_variant, sizeof(g_variant), "fwd_band<R%s,%s,%s,%s%s>x%d", R == 12 ? "1+2" : (R == 1 ? "1" : "2"), M == NFP_COSINE ? "cos" : "l2",
            BF ? "bf16" : "f32", NHWC ? "nhwc" : "nchw", POOL ? ",pool" : "", nb);
-  return launch("fwd_band", fwd_band<R, M, BF, NHWC, POOL>, dim3(g.B, nb), dim3(kBandT), lds, st, g, x, out, saved, g.ws,
+  return launch("fwd_band", fwd_band<R, M, BF, NHWC, POOL>, dim3(g.B, nb), dim3(T), lds, st, g, x, out, saved, g.ws,
                 rb, gap, nfpm);
 }
 
