@@ -497,6 +497,9 @@ int launch_fwd_band_t(KP g, const void* x, void* out, float* saved, hipStream_t 
                       float* nfpm = nullptr) {
   constexpr int NF = Win<R>::NF;
   int nb = std::min(g.H, (NFP_BAND_WGS + g.B - 1) / g.B);   // bands per image so that >= NFP_BAND_WGS workgroups exist
+  // two workgroups per CU overlap each other's load and sum phases — worth it while a band's R halo rows stay a small
+  // part of what it stages (14x14, k = 3 at B = 256: 12.8 -> 10.8 us; not 7x7: 7.3 -> 8.2 us)
+  nb = std::max(nb, std::min((2 * NFP_BAND_WGS + g.B - 1) / g.B, g.H / (6 * g.R)));
   if (POOL) nb = 1;   // the pooled outputs are sums over the whole image: one workgroup per image, nothing to combine
   const int rb = (g.H + nb - 1) / nb;
   nb = (g.H + rb - 1) / rb;
@@ -555,6 +558,9 @@ int launch_bwd_fast_t(KP g, const void* x, const void* go, const void* out, cons
 #define NFP_BWD_WGS 256
 #endif
   int S = (NFP_BWD_WGS + g.B - 1) / g.B;  // channel blocks per image so that >= NFP_BWD_WGS workgroups exist
+  // ... and twice as many while a workgroup's block stays large ([256,960,7,7]: 22.9 -> 21.5 us, [256,192,14,14]: 21.3 ->
+  // 20.2 us; not [256,512,7,7]: 13.8 -> 14.0 us): phase A is repeated per block, the streaming part is what splits
+  if ((long long)g.C * g.P / S >= 32768 && (long long)g.B * S < 2 * NFP_BWD_WGS) S = (2 * NFP_BWD_WGS + g.B - 1) / g.B;
   if (S > g.C / 4) S = g.C / 4;
   if (S < 1) S = 1;
   g.Cwg = round4((g.C + S - 1) / S);
