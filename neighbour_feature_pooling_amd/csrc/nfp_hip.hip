@@ -602,10 +602,10 @@ int launch_fwd_gram(const KP& g, const void* x, void* out, float* saved, hipStre
   snprintf(g_variant, sizeof(g_variant), "fwd_gram<R%d,%s,bf16,%s>", R, M == NFP_COSINE ? "cos" : "l2",
            g.contig ? "nchw" : "nhwc");
   if (g.contig)
-    return launch("fwd_gram", fwd_gram<R, M, true, true>, dim3(g.B), dim3(1024), tiles + image, st, g, x, out, saved, D);
+    return launch("fwd_gram", fwd_gram<R, M, true, true>, dim3(g.B), dim3(1024), tiles + image, st, g, x, out, saved, D, g.ws);
   if (tiles + image <= (size_t)kLdsMax)
-    return launch("fwd_gram", fwd_gram<R, M, true>, dim3(g.B), dim3(1024), tiles + image, st, g, x, out, saved, D);
-  return launch("fwd_gram", fwd_gram<R, M, false>, dim3(g.B), dim3(1024), tiles + (size_t)g.P * 8, st, g, x, out, saved, D);
+    return launch("fwd_gram", fwd_gram<R, M, true>, dim3(g.B), dim3(1024), tiles + image, st, g, x, out, saved, D, g.ws);
+  return launch("fwd_gram", fwd_gram<R, M, false>, dim3(g.B), dim3(1024), tiles + (size_t)g.P * 8, st, g, x, out, saved, D, g.ws);
 }
 
 // Phase B of the backward on the matrix cores (nfp_fast.h::bwd_gemm_phase): bf16 storage, C a multiple of 32.

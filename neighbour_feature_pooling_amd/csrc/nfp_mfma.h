@@ -28,7 +28,7 @@ constexpr int kGramLd = 33;  // row stride of a stored tile (floats): column rea
 // coalesced along the pixel axis, packed into one 16-byte LDS write); needs LDSX.
 template <int R, int M, bool LDSX, bool NCHW = false>
 __global__ void __launch_bounds__(1024) fwd_gram(const KP g, const void* __restrict__ x, void* __restrict__ out,
-                                                float* __restrict__ saved, int D) {
+                                                float* __restrict__ saved, int D, const unsigned char* __restrict__ ws) {
   constexpr int K = 2 * R + 1, N = K * K - 1;
   extern __shared__ __attribute__((aligned(16))) float Gt[];  // [nt * (D + 1)][32][kGramLd], then the image
   const int b = blockIdx.x, t = threadIdx.x, T = blockDim.x;
@@ -38,6 +38,13 @@ __global__ void __launch_bounds__(1024) fwd_gram(const KP g, const void* __restr
   const int rowq = (C >> 3) + 1;  // 16-byte pieces per LDS row (one of padding)
   uint4* xl = (uint4*)(Gt + ((nt * (D + 1) * 32 * kGramLd + 3) & ~3));
   static_assert(LDSX || !NCHW, "the NCHW variant transposes through LDS");
+  // output map: thread (p, n = gl, gl + G, ...).  Which pixel does tap n of pixel p read?  From the descriptor's
+  // workspace table `ft` (nfp_tables.h: low 9 bits = pixel, bits 22-23 = 2 for a zero-padded tap) when the caller has
+  // one — the first entry is loaded here, in flight during the tiles — else computed per thread
+  const int G = max(1, T / P), gl = fdivi(t, P), pr = t - gl * P;
+  const int p = gl < G ? pr : 0;  // (surplus threads idle through the barriers below)
+  const uint32_t* ftt = ws != nullptr ? (const uint32_t*)(ws + ws_layout(P, R, g.mode).ft) : nullptr;
+  const uint32_t fte = ftt != nullptr ? ftt[min(gl, N - 1) * P + p] : 0u;
   if (LDSX) {
     const int cq = C >> 3;  // pieces per pixel row
     if (NCHW) {
@@ -85,8 +92,6 @@ __global__ void __launch_bounds__(1024) fwd_gram(const KP g, const void* __restr
   __syncthreads();
 
   // ---- outputs: thread (p, n = gl, gl + G, ...), as fwd_fast ------------------------------------------------------
-  const int G = max(1, T / P), gl = fdivi(t, P), pr = t - gl * P;
-  const int p = gl < G ? pr : 0;  // (surplus threads idle through the barrier below)
   auto gram = [&](int a, int c) -> float {  // G[a][c] for pixels within the band
     const int ta = a >> 5, tc = c >> 5;
     const int lo = min(ta, tc), dd = abs(ta - tc);
@@ -95,7 +100,7 @@ __global__ void __launch_bounds__(1024) fwd_gram(const KP g, const void* __restr
   };
   const int py = fdivi(p, g.W), px = p - py * g.W;
   NbrMap<R> nm;
-  nm.init(g, py, px);
+  if (ftt == nullptr) nm.init(g, py, px);
   void* ob = (char*)out + (long long)b * N * P * 2;
   // per-pixel |x|^2 (and 1/max(|x|, eps) for cosine) once, in the LDS words behind the image / tiles' diagonal use
   float* n2t = (float*)xl;  // the image is dead: every tile is finished (barrier above)
@@ -109,8 +114,14 @@ __global__ void __launch_bounds__(1024) fwd_gram(const KP g, const void* __restr
   const float n2p = n2t[p];
   const float ip = M == NFP_COSINE ? n2t[P + p] : 0.f;
   for (int n = gl; n < N; n += G) {
-    int qy, qx;
-    const int q = nm.get(g, n, qy, qx);
+    int q;
+    if (ftt != nullptr) {
+      const uint32_t e = n == gl ? fte : ftt[n * P + p];
+      q = (e >> 22) == 2u ? -1 : (int)(e & 511u);
+    } else {
+      int qy, qx;
+      q = nm.get(g, n, qy, qx);
+    }
     const int qc = max(q, 0);
     const float n2q = n2t[qc], dot = gram(p, qc);
     float v;
