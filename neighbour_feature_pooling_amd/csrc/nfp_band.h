@@ -41,20 +41,6 @@ struct FoffQ {
 // Thread maps.  Channel sums: thread t = lp * G + gl — the G channel groups of a pixel are ADJACENT LANES (G a power
 // of two <= 32, g.G; g.Tc = log2 G), so the groups' partial sums are joined by a fixed DPP tree inside the wavefront:
 // no LDS round trip, no barrier.  Outputs: thread t = gl' * Ps + lp' — lanes along pixels, coalesced stores.
-// sum over the G adjacent lanes of a group (G a power of two <= 32); valid in the group's LAST lane (in every lane of
-// the group for G <= 16).  DPP lane exchanges: no LDS round trip, a fixed order.
-#define NFP_DPP_ADD(v, ctrl, rows) \
-  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, rows, 0xF, false))
-__device__ __forceinline__ float group_sum(float v, int G) {
-  if (G >= 2) NFP_DPP_ADD(v, 0xB1, 0xF);    // quad_perm [1,0,3,2]: lane ^ 1
-  if (G >= 4) NFP_DPP_ADD(v, 0x4E, 0xF);    // quad_perm [2,3,0,1]: lane ^ 2
-  if (G >= 8) NFP_DPP_ADD(v, 0x141, 0xF);   // row_half_mirror: the other quad of each 8 lanes
-  if (G >= 16) NFP_DPP_ADD(v, 0x140, 0xF);  // row_mirror: the other half of each row of 16
-  if (G >= 32) NFP_DPP_ADD(v, 0x142, 0xA);  // row_bcast15 into rows 1 and 3: the row before
-  return v;
-}
-#undef NFP_DPP_ADD
-
 template <int R, int M, bool BF, bool NHWC, bool POOL = false>
 __global__ void __launch_bounds__(1024) fwd_band(const KP g, const void* __restrict__ x, void* __restrict__ out,
                                                  float* __restrict__ saved, const unsigned char* __restrict__ ws,

@@ -110,4 +110,18 @@ __device__ __forceinline__ int fdivi(int i, int d) {
   return (int)(((float)i + 0.5f) * __builtin_amdgcn_rcpf((float)d));
 }
 
+// sum over the G adjacent lanes of a group (G a power of two <= 32); valid in the group's LAST lane (in every lane of
+// the group for G <= 16).  DPP lane exchanges: no LDS round trip, a fixed order.
+#define NFP_DPP_ADD(v, ctrl, rows) \
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, rows, 0xF, false))
+__device__ __forceinline__ float group_sum(float v, int G) {
+  if (G >= 2) NFP_DPP_ADD(v, 0xB1, 0xF);    // quad_perm [1,0,3,2]: lane ^ 1
+  if (G >= 4) NFP_DPP_ADD(v, 0x4E, 0xF);    // quad_perm [2,3,0,1]: lane ^ 2
+  if (G >= 8) NFP_DPP_ADD(v, 0x141, 0xF);   // row_half_mirror: the other quad of each 8 lanes
+  if (G >= 16) NFP_DPP_ADD(v, 0x140, 0xF);  // row_mirror: the other half of each row of 16
+  if (G >= 32) NFP_DPP_ADD(v, 0x142, 0xA);  // row_bcast15 into rows 1 and 3: the row before
+  return v;
+}
+#undef NFP_DPP_ADD
+
 }  // namespace nfp

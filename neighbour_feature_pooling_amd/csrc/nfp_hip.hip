@@ -590,7 +590,8 @@ int launch_bwd_fast_t(KP g, const void* x, const void* go, const void* out, cons
 bool mfma_enabled() { return g_sw.mfma.load(std::memory_order_relaxed) != 0; }
 
 template <int R, int M>
-int launch_fwd_gram(const KP& g, const void* x, void* out, float* saved, hipStream_t st) {
+int launch_fwd_gram(const KP& g, const void* x, void* out, float* saved, hipStream_t st, float* gap = nullptr,
+                    float* nfpm = nullptr) {
   if (!mfma_enabled() || g.dtype != NFP_BF16 || (g.C & 15) || g.P > 512) return kNotApplicable;
   if (!g.contig && (((uintptr_t)x & 15) || ((g.sB * 2) & 15))) return kNotApplicable;  // 16-byte fragment loads
   const int nt = (g.P + 31) / 32, D = std::min(nt - 1, (g.R * g.W + g.R + 31) / 32);
@@ -599,13 +600,18 @@ int launch_fwd_gram(const KP& g, const void* x, void* out, float* saved, hipStre
   if (tiles > (size_t)kLdsMax) return kNotApplicable;
   if (g.contig && tiles + image > (size_t)kLdsMax) return kNotApplicable;  // NCHW is transposed through LDS only
   if (tiles + (size_t)g.P * 8 > (size_t)kLdsMax) return kNotApplicable;  // (the norm tables reuse the image's words)
-  snprintf(g_variant, sizeof(g_variant), "fwd_gram<R%d,%s,bf16,%s>", R, M == NFP_COSINE ? "cos" : "l2",
-           g.contig ? "nchw" : "nhwc");
+  // the pooled variant takes its sums from the LDS image and stages the map values in it afterwards
+  if (gap != nullptr && (tiles + image > (size_t)kLdsMax || image < (size_t)(2 + Win<R>::N) * g.P * 4)) return kNotApplicable;
+  snprintf(g_variant, sizeof(g_variant), "fwd_gram<R%d,%s,bf16,%s%s>", R, M == NFP_COSINE ? "cos" : "l2",
+           g.contig ? "nchw" : "nhwc", gap != nullptr ? ",pool" : "");
   if (g.contig)
-    return launch("fwd_gram", fwd_gram<R, M, true, true>, dim3(g.B), dim3(1024), tiles + image, st, g, x, out, saved, D, g.ws);
+    return launch("fwd_gram", fwd_gram<R, M, true, true>, dim3(g.B), dim3(1024), tiles + image, st, g, x, out, saved, D, g.ws,
+                  gap, nfpm);
   if (tiles + image <= (size_t)kLdsMax)
-    return launch("fwd_gram", fwd_gram<R, M, true>, dim3(g.B), dim3(1024), tiles + image, st, g, x, out, saved, D, g.ws);
-  return launch("fwd_gram", fwd_gram<R, M, false>, dim3(g.B), dim3(1024), tiles + (size_t)g.P * 8, st, g, x, out, saved, D, g.ws);
+    return launch("fwd_gram", fwd_gram<R, M, true>, dim3(g.B), dim3(1024), tiles + image, st, g, x, out, saved, D, g.ws, gap,
+                  nfpm);
+  return launch("fwd_gram", fwd_gram<R, M, false>, dim3(g.B), dim3(1024), tiles + (size_t)g.P * 8, st, g, x, out, saved, D, g.ws,
+                (float*)nullptr, (float*)nullptr);
 }
 
 // Phase B of the backward on the matrix cores (nfp_fast.h::bwd_gemm_phase): bf16 storage, C a multiple of 32.
@@ -860,6 +866,10 @@ int backward_impl(const nfp_desc* d, const void* x, const void* grad_out, const 
 template <int R, int M>
 int pool_forward_rm(const KP& g, const void* x, void* out_map, float* saved, hipStream_t st, float* gap, float* nfpm) {
   const bool bf = g.dtype == NFP_BF16, nhwc = !g.contig;
+  if (bf) {  // the matrix-core forward where it applies, as in nfp_forward
+    const int rc = launch_fwd_gram<R, M>(g, x, out_map, saved, st, gap, nfpm);
+    if (rc != kNotApplicable) return rc;
+  }
   if (bf) return nhwc ? launch_fwd_band_t<R, M, true, true, true>(g, x, out_map, saved, st, gap, nfpm)
                       : launch_fwd_band_t<R, M, true, false, true>(g, x, out_map, saved, st, gap, nfpm);
   return nhwc ? launch_fwd_band_t<R, M, false, true, true>(g, x, out_map, saved, st, gap, nfpm)

@@ -27,8 +27,11 @@ constexpr int kGramLd = 33;  // row stride of a stored tile (floats): column rea
 // NCHW: bf16 NCHW input, transposed into the same LDS image (thread = (pixel, 8 channels): eight 2-byte loads,
 // coalesced along the pixel axis, packed into one 16-byte LDS write); needs LDSX.
 template <int R, int M, bool LDSX, bool NCHW = false>
+// gap / nfpm non-null (LDSX only) = the fused tail of models/NFP_Pooling.py:27-31: gap[b,c] = mean over pixels of x,
+// taken from the LDS image; nfpm[b,n] = mean over pixels of the map values (before their bf16 rounding).
 __global__ void __launch_bounds__(1024) fwd_gram(const KP g, const void* __restrict__ x, void* __restrict__ out,
-                                                float* __restrict__ saved, int D, const unsigned char* __restrict__ ws) {
+                                                float* __restrict__ saved, int D, const unsigned char* __restrict__ ws,
+                                                float* __restrict__ gap, float* __restrict__ nfpm) {
   constexpr int K = 2 * R + 1, N = K * K - 1;
   extern __shared__ __attribute__((aligned(16))) float Gt[];  // [nt * (D + 1)][32][kGramLd], then the image
   const int b = blockIdx.x, t = threadIdx.x, T = blockDim.x;
@@ -68,6 +71,32 @@ __global__ void __launch_bounds__(1024) fwd_gram(const KP g, const void* __restr
       }
     }
     __syncthreads();
+    if (gap != nullptr) {
+      // channel means: 32 adjacent lanes per channel octet, lane `part` sums pixels part, part + 32, ...; fixed DPP tree
+      const int cq = C >> 3, part = t & 31;
+      for (int k0 = 0; k0 < cq; k0 += T >> 5) {
+        const int k = min(k0 + (t >> 5), cq - 1);
+        float s8[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s8[u] = 0.f;
+        for (int pp = part; pp < P; pp += 32) {
+          const uint4 w = xl[pp * rowq + k];
+          const uint32_t wd[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            s8[2 * u] += __uint_as_float(wd[u] << 16);
+            s8[2 * u + 1] += __uint_as_float(wd[u] & 0xFFFF0000u);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s8[u] = group_sum(s8[u], 32) * g.invP;
+        if (part == 31 && k0 + (t >> 5) < cq) {
+          float4* dst = (float4*)(gap + (long long)b * C + 8 * k);
+          dst[0] = make_float4(s8[0], s8[1], s8[2], s8[3]);
+          dst[1] = make_float4(s8[4], s8[5], s8[6], s8[7]);
+        }
+      }
+    }
   }
 
   // ---- Gram tiles: tile pair (i, j = i + d), one wavefront each ---------------------------------------------
@@ -110,10 +139,10 @@ __global__ void __launch_bounds__(1024) fwd_gram(const KP g, const void* __restr
     if (M == NFP_COSINE) n2t[P + p] = inv_norm(d, g.inv_eps);
   }
   __syncthreads();
-  if (gl >= G) return;
+  float* vm = n2t + 2 * P;  // [N][P] map values for the pooled means (inside the dead image)
   const float n2p = n2t[p];
   const float ip = M == NFP_COSINE ? n2t[P + p] : 0.f;
-  for (int n = gl; n < N; n += G) {
+  for (int n = gl; n < (gl < G ? N : 0); n += G) {
     int q;
     if (ftt != nullptr) {
       const uint32_t e = n == gl ? fte : ftt[n * P + p];
@@ -138,8 +167,19 @@ __global__ void __launch_bounds__(1024) fwd_gram(const KP g, const void* __restr
       v = g.similarity ? -dd : dd;
     }
     stx(ob, n * P + p, v, NFP_BF16);
+    if (nfpm != nullptr) vm[n * P + p] = v;
   }
   if (M == NFP_COSINE && saved != nullptr && gl == 0) saved[(long long)b * P + p] = __builtin_amdgcn_sqrtf(n2p);
+  if (nfpm != nullptr) {
+    __syncthreads();
+    // wave w reduces map n = w, w + nwaves, ...: lane-strided partial sums, then a fixed shuffle tree
+    for (int n = wave; n < N; n += T >> 6) {
+      float sacc = 0.f;
+      for (int i = lane; i < P; i += 64) sacc += vm[n * P + i];
+      for (int m = 32; m >= 1; m >>= 1) sacc += __shfl_xor(sacc, m);
+      if (lane == 0) nfpm[(long long)b * N + n] = sacc * g.invP;
+    }
+  }
 }
 
 }  // namespace nfp

@@ -400,7 +400,8 @@ def test_fused_pool_matches_composition(shape, ctor, layout, dtype, dev):
     x2 = x0.detach().float().contiguous().requires_grad_(True)     # composition in float32 on the same (rounded) input
     gap, nfpm = nfp_pool(x1, m.config)
     fv = _abi.load().nfp_last_variant().decode()
-    assert fv.startswith("fwd_band<") and ",pool>" in fv and (",nhwc" in fv) == (layout == "nhwc"), fv
+    assert fv.startswith(("fwd_band<", "fwd_gram<")) and ",pool>" in fv and (",nhwc" in fv) == (layout == "nhwc"), fv
+    assert fv.startswith("fwd_gram<") == (bf and shape[1] % 16 == 0 and shape[1] >= 48), fv   # bf16: the matrix cores
     ref_gap, ref_nfpm = x2.mean((2, 3)), nfp(x2, m.config).mean((2, 3))
     tol_f, tol_b = (1e-2, 2e-2) if bf else (2e-6, 1e-5)
     assert rel_err(gap.detach().float().cpu().numpy(), ref_gap.detach().cpu().numpy()) <= tol_f
@@ -444,7 +445,7 @@ def test_nfp_pooling_wrapper_on_gpu_matches_reference_golden(dev):
     xb = x.detach().to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
     yb = wb(xb)
     fv = _abi.load().nfp_last_variant().decode()
-    assert fv.startswith("fwd_band<R1,cos,bf16,nhwc,pool>"), fv
+    assert fv.startswith("fwd_gram<R1,cos,bf16,nhwc,pool>"), fv
     yb.backward(torch.from_numpy(feature_map((B, C), 203)).to(dev).to(torch.bfloat16))
     assert rel_err(yb.detach().float().cpu().numpy(), g["y"]) <= 3e-2
     assert rel_err(xb.grad.float().cpu().numpy(), g["gx"]) <= 3e-2
