@@ -7,7 +7,7 @@
   on the GPU box:        python scripts/ab_flags.py --run
       times every library of the manifest round-robin (2 rounds) in fresh subprocesses
 
-Optional env for --run: AB_SHAPE="64,512,7,1,cosine[,bf16][,nhwc]"  (B,C,S,R,measure)
+Optional env for --run: AB_SHAPE="64,512,7,1,cosine[,bf16][,nhwc]"  (B,C,S,R,measure); AB_COLD=1 adds the rotating-set leg
 """
 import concurrent.futures as cf
 import json
@@ -67,6 +67,15 @@ with torch.cuda.stream(s):
     bv = _abi.load().nfp_last_variant().decode()
     tf = time_kernel_graph(lambda: m(x), 50, s)
     tb = time_kernel_graph(lambda: torch.autograd.grad(out, x, go, retain_graph=True), 50, s)
+if os.environ.get("AB_COLD"):   # rotating sets behind a cache flush (bench.py's cold protocol) instead of one resident set
+    import bench
+    a = bench.parse(["--batch", "{B}", "--channels", "{C}", "--size", "{S}", "--radius", "{R}", "--measure", {meas!r},
+                     "--dtype", "bf16" if {bf16} else "f32", "--layout", "nhwc" if {nhwc} else "nchw"])
+    w = bench.Workload(a, torch.device("cuda", 0), 0)
+    with torch.cuda.stream(s):
+        cf_, cb_ = w.kernel_times(s)
+        _, cbi = w.kernel_times(s, isolated_backward=True)
+    print(f"[{{{tag!r}:44s}}] cold: fwd {{cf_:6.2f}} us   bwd in step {{cb_:6.2f}} us   bwd alone {{cbi:6.2f}} us")
 print(f"[{{{tag!r}:44s}}] fwd {{tf:6.2f}} us   bwd {{tb:6.2f}} us   sum {{tf+tb:6.2f}}   {{fv}} / {{bv}}")
 """
 
