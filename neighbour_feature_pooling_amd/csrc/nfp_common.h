@@ -39,11 +39,14 @@ struct KP {
 };
 
 __device__ __forceinline__ float bf16_to_f32(uint16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
-__device__ __forceinline__ uint16_t f32_to_bf16(float f) {
-  // round-to-nearest-even, NaN kept a NaN
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
-  return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+// round-to-nearest-even, NaN kept a NaN: gfx950 converts in hardware (v_cvt_pk_bf16_f32; the integer formula with its
+// NaN branch cost ~10 instructions and an exec-mask branch per element of every bf16 store)
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) { return __builtin_bit_cast(uint16_t, (__bf16)f); }
+__device__ __forceinline__ uint32_t f32_to_bf16x2(float lo, float hi) {  // one instruction: {lo, hi} packed
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  const f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
 __device__ __forceinline__ float ldx(const void* x, long long i, int dtype) {
   return dtype == NFP_F32 ? ((const float*)x)[i] : bf16_to_f32(((const uint16_t*)x)[i]);

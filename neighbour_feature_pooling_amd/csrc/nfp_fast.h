@@ -92,8 +92,8 @@ __device__ __forceinline__ void store_px4(Rsrc r, int e, int srow, float4 v) {  
     u32x4 u = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
     __builtin_amdgcn_raw_buffer_store_b128(u, r, e * 4, srow * 4, NFP_BWD_STORE_AUX);
   } else {
-    u32x2 u = {(uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16),
-               (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16)};
+    u32x2 u = {f32_to_bf16x2(v.x, v.y),
+               f32_to_bf16x2(v.z, v.w)};
     __builtin_amdgcn_raw_buffer_store_b64(u, r, e * 2, srow * 2, NFP_BWD_STORE_AUX);
   }
 }
@@ -188,67 +188,108 @@ __device__ __forceinline__ float inv_norm(float n2, float inv_eps) {
 // Row tiles are processed a few at a time (Wd of all of them does not fit next to Xt at config 5's shape: g.Tc).
 __device__ __forceinline__ int odd_up(int v) { return v | 1; }
 
-// gg: grad of the pooled channel means of this image (fused pooling tail) or null: every grad_x[c][p] also gets gg[c]/P.
-template <int R, bool NHWC>
-__device__ __forceinline__ void bwd_gemm_phase(const KP& g, const float* Wt, uint4* scratch, const uint16_t* xb,
-                                               uint16_t* gxb, int cb0, int cb1, int t, int T, const float* gg = nullptr) {
-  constexpr int K = Win<R>::K, K2 = Win<R>::K2;
-  const int P = g.P, C = g.C, band = R * g.W + R, nt = (P + 31) >> 5;
-  const int KW = (32 + 2 * band + 15 + 15) >> 4;            // k-steps that cover a row tile's window after aligning its start
-  const int xq = odd_up(((P + 15) >> 4 << 1) + 1);          // 16-byte pieces per Xt row: P rounded up to 16 pixels, + padding, odd
-  const int wq = odd_up(2 * KW + 1);                        // pieces per Wd row
-  const int ncw = cb1 - cb0;                                // channels of this workgroup (multiple of 32)
-  uint4* Xt = scratch;                                      // [ncw][xq]
-  uint4* Wd = Xt + (long long)ncw * xq;                     // [2 row tiles][hi, lo][32][wq]
-  const int lane = t & 63, wave = t >> 6, nw = T >> 6, r = lane & 31, h = lane >> 5;
-
-  // ---- Xt: 8 consecutive pixels of one channel per 16-byte piece; pixels past P are zero ------------------
-  const int pg = (P + 7) >> 3;
-  if (NHWC) {
-    // 8 pixels x 8 channels per step: eight 16-byte loads (one per pixel), transposed in registers into eight
-    // pieces (one per channel)
-    const int co = ncw >> 3;
-    for (int i = t; i < pg * co; i += T) {
-      const int gq = fdivi(i, co), k = i - gq * co;  // channel octet fastest: coalesced
-      uint4 v[8];
+// ---- Xt: 8 consecutive pixels of one channel per 16-byte piece; pixels past P are zero --------------------------
+// The image block arrives 2-3 us after it is asked for, whatever the cache level, so each thread asks for its FIRST
+// share as soon as phase A has its pair values (gemm_x_issue; every table row the gathers need was requested at entry:
+// loads retire in order) and holds it in registers until the pair values under Xt are dead; gemm_stage_x then writes
+// that share and fetches the rest.
+// NHWC: 8 pixels x 8 channels per item: eight 16-byte loads (one per pixel), transposed in registers (v_perm_b32)
+// into eight pieces (one per channel).  A wavefront takes a block of 4 channel octets x 16 pixel groups, laid on its
+// lanes so that every 16 lanes write 2 octets x 8 groups: Xt rows are an odd number of pieces apart, so lanes along
+// the octets — what the loads would like — land on two 16-byte LDS slots (measured: 3.7 of 21 us at config 5).
+// NCHW with P % 4 == 0: a piece is two 8-byte loads, four pieces per thread.  NCHW with odd rows: 2-byte loads, not
+// issued early.
+__device__ __forceinline__ int gemm_xq(int P) { return odd_up(((P + 15) >> 4 << 1) + 1); }  // pieces per Xt row: P rounded up to 16 pixels, + padding, odd
+constexpr int kGemmPre = 4;  // gather rounds whose table rows the matrix-core backward requests at entry
+template <bool NHWC>
+struct GemmX {
+  uint4 v[NHWC ? 8 : 4];
+};
+__device__ __forceinline__ void gemm_block_of(int blk, int co4, int lane, int& k, int& gq) {
+  const int bq = fdivi(blk, co4), bk = blk - bq * co4;
+  k = 4 * bk + (lane & 1) + ((lane >> 3) & 2);
+  gq = 16 * bq + ((lane >> 1) & 7) + ((lane >> 2) & 8);
+}
+__device__ __forceinline__ void gemm_fetch8(uint4 (&v)[8], const KP& g, const uint16_t* xb, int cb0, int k, int gq) {
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int pp = min(8 * gq + u, P - 1);
-        v[u] = *(const uint4*)(xb + (long long)pp * C + cb0 + 8 * k);
+  for (int u = 0; u < 8; ++u) v[u] = *(const uint4*)(xb + (long long)min(8 * gq + u, g.P - 1) * g.C + cb0 + 8 * k);
+}
+__device__ __forceinline__ void gemm_fetch_row(uint4& v, const KP& g, const uint16_t* xb, int cb0, int pg, int i) {
+  const int c = fdivi(i, pg), gs = i - c * pg;
+  const uint16_t* src = xb + (long long)(cb0 + c) * g.P + 8 * gs;
+  const uint2 lo = *(const uint2*)src;
+  const uint2 hi = 8 * gs + 4 < g.P ? *(const uint2*)(src + 4) : make_uint2(0, 0);  // (P % 4 == 0: a whole half or none)
+  v = make_uint4(lo.x, lo.y, hi.x, hi.y);
+}
+template <bool NHWC>
+__device__ __forceinline__ void gemm_x_issue(GemmX<NHWC>& s, const KP& g, const uint16_t* xb, int cb0, int ncw, int t, int T) {
+  const int P = g.P, pg = (P + 7) >> 3;
+  if constexpr (NHWC) {
+    const int co4 = ncw >> 5, nblk = co4 * ((pg + 15) >> 4);
+    int k, gq;
+    gemm_block_of(min(__builtin_amdgcn_readfirstlane(t >> 6), nblk - 1), co4, t & 63, k, gq);
+    gemm_fetch8(s.v, g, xb, cb0, k, min(gq, pg));
+  } else if ((P & 3) == 0) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) gemm_fetch_row(s.v[u], g, xb, cb0, pg, min(t + u * T, ncw * pg - 1));
+  }
+}
+template <bool NHWC>
+__device__ __forceinline__ void gemm_stage_x(const KP& g, uint4* Xt, const uint16_t* xb, int cb0, int ncw, int t, int T,
+                                             GemmX<NHWC>& pre) {
+  const int P = g.P, pg = (P + 7) >> 3, xq = gemm_xq(P);
+  const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), nw = T >> 6;  // (wave-uniform, in an SGPR)
+  if constexpr (NHWC) {
+    const int co4 = ncw >> 5, nblk = co4 * ((pg + 15) >> 4);
+    auto commit = [&](uint4 (&v)[8], int k, int gq) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
         if (8 * gq + u >= P) v[u] = make_uint4(0, 0, 0, 0);
-      }
 #pragma unroll
       for (int j = 0; j < 8; ++j) {  // channel 8k + j: its 16 bits of every pixel's piece
-        uint32_t e[8];
+        uint32_t e[4];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const uint32_t wd = (j >> 1) == 0 ? v[u].x : ((j >> 1) == 1 ? v[u].y : ((j >> 1) == 2 ? v[u].z : v[u].w));
-          e[u] = (j & 1) ? (wd >> 16) : (wd & 0xFFFFu);
+        for (int u = 0; u < 4; ++u) {
+          const uint4 &a = v[2 * u], &b = v[2 * u + 1];
+          const uint32_t wa = (j >> 1) == 0 ? a.x : ((j >> 1) == 1 ? a.y : ((j >> 1) == 2 ? a.z : a.w));
+          const uint32_t wb = (j >> 1) == 0 ? b.x : ((j >> 1) == 1 ? b.y : ((j >> 1) == 2 ? b.z : b.w));
+          e[u] = __builtin_amdgcn_perm(wb, wa, (j & 1) ? 0x07060302u : 0x05040100u);  // {pixel 2u, pixel 2u + 1}
         }
-        Xt[(long long)(8 * k + j) * xq + gq] =
-            make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
+        if (gq < pg) Xt[(long long)(8 * k + j) * xq + gq] = make_uint4(e[0], e[1], e[2], e[3]);
       }
+    };
+    int k, gq;
+    if (wave < nblk) {  // the block requested at kernel entry
+      gemm_block_of(wave, co4, lane, k, gq);
+      commit(pre.v, k, min(gq, pg));
+    }
+    for (int blk = wave + nw; blk < nblk; blk += nw) {
+      uint4 v[8];
+      gemm_block_of(blk, co4, lane, k, gq);
+      gq = min(gq, pg);  // (group pg: loads clamp to the last pixel, nothing is written)
+      gemm_fetch8(v, g, xb, cb0, k, gq);
+      commit(v, k, gq);
     }
   } else if ((P & 3) == 0) {
-    // NCHW rows are 8-byte aligned: a piece is two 8-byte loads; four pieces in flight per thread
-    for (int i0 = t; i0 < ncw * pg; i0 += 4 * T) {
-      uint2 lo[4], hi[4];
-      int cs[4], gs[4];
+    const int np = ncw * pg;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {  // the pieces requested at kernel entry
+      const int i = t + u * T, c = fdivi(i, pg);
+      if (i < np) Xt[(long long)c * xq + (i - c * pg)] = pre.v[u];
+    }
+    for (int i0 = t + 4 * T; i0 < np; i0 += 4 * T) {
+      uint4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) gemm_fetch_row(v[u], g, xb, cb0, pg, min(i0 + u * T, np - 1));
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const int i = min(i0 + u * T, ncw * pg - 1);
-        cs[u] = fdivi(i, pg);
-        gs[u] = i - cs[u] * pg;
-        const uint16_t* src = xb + (long long)(cb0 + cs[u]) * P + 8 * gs[u];
-        lo[u] = *(const uint2*)src;
-        hi[u] = 8 * gs[u] + 4 < P ? *(const uint2*)(src + 4) : make_uint2(0, 0);  // (P % 4 == 0: a whole half or none)
+        const int i = i0 + u * T, c = fdivi(i, pg);
+        if (i < np) Xt[(long long)c * xq + (i - c * pg)] = v[u];
       }
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-        if (i0 + u * T < ncw * pg) Xt[(long long)cs[u] * xq + gs[u]] = make_uint4(lo[u].x, lo[u].y, hi[u].x, hi[u].y);
     }
   } else {
-    for (int i = t; i < ncw * pg; i += T) {
+    const int np = ncw * pg;
+    for (int i = t; i < np; i += T) {
       const int c = fdivi(i, pg), gq = i - c * pg;  // pixel group fastest
       uint32_t v[8];
 #pragma unroll
@@ -260,19 +301,41 @@ __device__ __forceinline__ void bwd_gemm_phase(const KP& g, const float* Wt, uin
       Xt[(long long)c * xq + gq] = make_uint4(v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16));
     }
   }
+}
+
+// gg: grad of the pooled channel means of this image (fused pooling tail) or null: every grad_x[c][p] also gets gg[c]/P.
+// Xt, Wd: the two operand images in LDS (placed by bwd_fast); pre: the share of x requested at kernel entry.
+template <int R, bool NHWC>
+__device__ __forceinline__ void bwd_gemm_phase(const KP& g, const float* Wt, uint4* Xt, uint4* Wd, GemmX<NHWC>& pre,
+                                               const uint16_t* xb, uint16_t* gxb, int cb0, int cb1, int t, int T,
+                                               const float* gg = nullptr) {
+  constexpr int K = Win<R>::K, K2 = Win<R>::K2;
+  const int P = g.P, C = g.C, band = R * g.W + R, nt = (P + 31) >> 5;
+  const int KW = (32 + 2 * band + 15 + 15) >> 4;            // k-steps that cover a row tile's window after aligning its start
+  const int xq = gemm_xq(P);                                // 16-byte pieces per Xt row
+  const int wq = odd_up(2 * KW + 1);                        // pieces per Wd row
+  const int ncw = cb1 - cb0;                                // channels of this workgroup (multiple of 32)
+  const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), nw = T >> 6, r = lane & 31, h = lane >> 5;
+  NFP_STAMP_INIT();  // (diagnostic build: stamps 7.. of the first two rounds)
+  const int pg = (P + 7) >> 3;
+  gemm_stage_x<NHWC>(g, Xt, xb, cb0, ncw, t, T, pre);
   for (int i = t; i < ncw * (xq - pg); i += T) {  // the rest of every row (alignment + padding) reads as zero
     const int c = fdivi(i, xq - pg), k = i - c * (xq - pg);
     Xt[(long long)c * xq + pg + k] = make_uint4(0, 0, 0, 0);
   }
 
+  NFP_STAMP(7);
   const int nct = ncw >> 5;
   const int RT = g.Tc;  // row tiles per round: as many as fit in LDS next to Xt (launcher), at least 2
   for (int i0 = 0; i0 < nt; i0 += RT) {
     const int nrt = min(RT, nt - i0);
     __syncthreads();  // Xt staged / previous Wd consumed
+    if (i0 == 0) NFP_STAMP(8);
+    if (i0 == RT) NFP_STAMP(12);
     // ---- Wd for row tiles i0, i0 + 1: zero, then scatter the window slots of each row -----------------------
     for (int i = t; i < nrt * 2 * 32 * wq; i += T) Wd[i] = make_uint4(0, 0, 0, 0);
     __syncthreads();
+    if (i0 == 0) NFP_STAMP(9);
     for (int i = t; i < nrt * 32 * K2; i += T) {
       const int ri = fdivi(i, 32 * K2), rem = i - ri * 32 * K2, row = fdivi(rem, K2), j = rem - row * K2;
       const int rr = 32 * (i0 + ri) + row;
@@ -292,6 +355,7 @@ __device__ __forceinline__ void bwd_gemm_phase(const KP& g, const float* Wt, uin
       }
     }
     __syncthreads();
+    if (i0 == 0) NFP_STAMP(10);
     // ---- output tiles (row tile, channel tile), one wavefront each -----------------------------------------------
     for (int ot = wave; ot < nrt * nct; ot += nw) {
       const int ri = fdivi(ot, nct), ct = ot - ri * nct;
@@ -328,8 +392,8 @@ __device__ __forceinline__ void bwd_gemm_phase(const KP& g, const float* Wt, uin
 #pragma unroll
           for (int gq = 0; gq < 4; ++gq) {
             uint2 w;
-            w.x = (uint32_t)f32_to_bf16(acc[4 * gq]) | ((uint32_t)f32_to_bf16(acc[4 * gq + 1]) << 16);
-            w.y = (uint32_t)f32_to_bf16(acc[4 * gq + 2]) | ((uint32_t)f32_to_bf16(acc[4 * gq + 3]) << 16);
+            w.x = f32_to_bf16x2(acc[4 * gq], acc[4 * gq + 1]);
+            w.y = f32_to_bf16x2(acc[4 * gq + 2], acc[4 * gq + 3]);
             *(uint2*)(gxb + (long long)pp * C + cb0 + 32 * ct + 8 * gq + 4 * h) = w;
           }
         }
@@ -339,8 +403,8 @@ __device__ __forceinline__ void bwd_gemm_phase(const KP& g, const float* Wt, uin
         for (int gq = 0; gq < 4; ++gq) {
           if (32 * it + 8 * gq + 4 * h < P) {  // (P % 4 == 0: a whole group or none)
             uint2 w;
-            w.x = (uint32_t)f32_to_bf16(acc[4 * gq]) | ((uint32_t)f32_to_bf16(acc[4 * gq + 1]) << 16);
-            w.y = (uint32_t)f32_to_bf16(acc[4 * gq + 2]) | ((uint32_t)f32_to_bf16(acc[4 * gq + 3]) << 16);
+            w.x = f32_to_bf16x2(acc[4 * gq], acc[4 * gq + 1]);
+            w.y = f32_to_bf16x2(acc[4 * gq + 2], acc[4 * gq + 3]);
             *(uint2*)(dst + 8 * gq) = w;
           }
         }
@@ -353,7 +417,9 @@ __device__ __forceinline__ void bwd_gemm_phase(const KP& g, const float* Wt, uin
         }
       }
     }
+    if (i0 == 0) NFP_STAMP(11);
   }
+  NFP_STAMP(6);
 }
 
 template <int R>
@@ -390,6 +456,10 @@ __global__ void __launch_bounds__(GEMM ? 1024 : kBwdThreads) bwd_fast(const KP g
   float4* slab = g.early ? pv4 + (((M == NFP_COSINE ? 2 : 1) * N * P + 3) >> 2) : pv4;  // [Cc/4][P]
   const int b = blockIdx.x, t = threadIdx.x, T = blockDim.x;
   const int cb0 = blockIdx.y * g.Cwg, cb1 = min(g.C, cb0 + g.Cwg);
+  // matrix-core variant: Xt over the pair values (dead once Wt is built), Wd behind it
+  uint4* gemm_Xt = (uint4*)pv4;
+  uint4* gemm_Wd = gemm_Xt + (long long)(cb1 - cb0) * gemm_xq(P);
+  const uint16_t* x16 = (const uint16_t*)x + (long long)b * g.sB;
   const int gl = fast_div(t, g.invP), p = t - gl * P;
   const bool active = gl < g.G;
   constexpr int ES = BF ? 2 : 4;
@@ -422,28 +492,42 @@ __global__ void __launch_bounds__(GEMM ? 1024 : kBwdThreads) bwd_fast(const KP g
   };
   uint4 rw0, rw1;
   uint32_t tqv;
-  auto rows_load = [&](int e) {
-    rw0 = lnk[(long long)e * LQ];
-    rw1 = lnk[(long long)e * LQ + LQ - 1];  // (unconditional: the same piece again when a row is one piece)
-    tqv = tqt[e];
+  const uint4 kNoLinks = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+  auto rows_load_to = [&](uint4& d0, uint4& d1, uint32_t& dq, int e) {
+    d0 = lnk[(long long)e * LQ];
+    if (LQ > 1)  // (wave-uniform; a one-piece row read twice is 16 of the 34 bytes per entry the texture path moves)
+      d1 = lnk[(long long)e * LQ + LQ - 1];
+    else
+      d1 = kNoLinks;
+    dq = tqt[e];
   };
+  auto rows_load = [&](int e) { rows_load_to(rw0, rw1, tqv, e); };
   // grad_out / out of this image, 16 bytes per thread and round: VP consecutive pairs (N is a multiple of 8, so
   // N*P values are whole 16-byte pieces and every image's maps start on one)
   constexpr int VP = BF ? 8 : 4;
-  uint4 gq, oq;
-  auto pair_load = [&](int o) {  // o: first pair of the piece
-    if constexpr (!POOL) gq = *(const uint4*)((const char*)gob + (long long)o * ES);
-    oq = *(const uint4*)((const char*)outb + (long long)o * ES);
+  uint4 gq, oq, gq0, oq0;  // (the first round's piece in registers of its own: a copy made before the x block is
+                           // requested would wait for the data there)
+  auto pair_load_to = [&](uint4& gd, uint4& od, int o) {  // o: first pair of the piece
+    if constexpr (!POOL) gd = *(const uint4*)((const char*)gob + (long long)o * ES);
+    od = *(const uint4*)((const char*)outb + (long long)o * ES);
   };
+  auto pair_load = [&](int o) { pair_load_to(gq, oq, o); };
   auto pair_value = [&](const uint4& q, int k) {  // element k of a 16-byte piece
     const uint32_t wd = ((const uint32_t*)&q)[BF ? k >> 1 : k];
     return BF ? __uint_as_float(k & 1 ? wd & 0xFFFF0000u : wd << 16) : __uint_as_float(wd);
   };
-  {
+  // The matrix-core variant asks for its x block at entry and loads retire in order: every table row of the first
+  // PRE gather rounds is requested before it (PRE rounds cover config 5's 2548 entries on 1024 threads; the launcher
+  // picks the thread count so that they cover the table: kGemmPre).
+  constexpr int PRE = GEMM ? kGemmPre : 1;
+  uint4 prw0[PRE], prw1[PRE];
+  uint32_t ptq[PRE];
+#pragma unroll
+  for (int k = 0; k < PRE; ++k) {
     int r_, j_;
-    rows_load(entry_of(min(t, NE - 1), r_, j_));
+    rows_load_to(prw0[k], prw1[k], ptq[k], entry_of(min(t + k * T, NE - 1), r_, j_));
   }
-  pair_load(min(t * VP, NO - VP));
+  pair_load_to(gq0, oq0, min(t * VP, NO - VP));
   const float nrm = (M == NFP_COSINE) ? saved[(long long)b * P + min(t, P - 1)] : 0.f;
   uint4 bo[L_BRQ<R>::v];  // this pixel's window offsets (phase B)
   if constexpr (!GEMM) {
@@ -465,15 +549,16 @@ __global__ void __launch_bounds__(GEMM ? 1024 : kBwdThreads) bwd_fast(const KP g
     else
       stage_store_ovl(st, slab, g, ncq, t, T);
   };
+  GemmX<NHWC> gxr;
   if constexpr (!GEMM) x_issue(cb0, min(g.Cc, cb1 - cb0) >> 2);
   // nothing that consumes a loaded value may be scheduled above this line (hipcc otherwise hoists consumers into
   // the load sequence and stalls the remaining loads behind a vmcnt wait)
   __builtin_amdgcn_sched_barrier(0);
   NFP_STAMP(1);
   // A1: per-pair values, in the memory order of grad_out / out
-  for (int o = t * VP; o < NO; o += T * VP) {
-    const uint4 gc4 = gq, oc4 = oq;
-    if (o + T * VP < NO) pair_load(o + T * VP);
+  // (first round outside the loop: hipcc's wait-count pass is exact in straight-line code only, and a wait that
+  // also covers the x block just requested would put its whole latency in front of phase A)
+  auto pair_round = [&](int o, const uint4& gc4, const uint4& oc4) {
 #pragma unroll
     for (int k = 0; k < VP; ++k) {
       const float oc = pair_value(oc4, k);
@@ -487,6 +572,20 @@ __global__ void __launch_bounds__(GEMM ? 1024 : kBwdThreads) bwd_fast(const KP g
         CC[o + k] = d == 0.f ? 0.f : (g.similarity ? -gc : gc) * __builtin_amdgcn_rcpf(d);
       }
     }
+  };
+  // The matrix-core variant has NO loop that loads from memory between here and the commit of its x block (the
+  // launcher guarantees one pair round and at most PRE gather rounds): after such a loop the wait-count pass no
+  // longer knows how many loads are in flight and waits for all of them, the x block included.
+  if constexpr (!GEMM) {
+    if ((t + T) * VP < NO) pair_load((t + T) * VP);
+  }
+  if (t * VP < NO) pair_round(t * VP, gq0, oq0);
+  if constexpr (!GEMM) {
+    for (int o = (t + T) * VP; o < NO; o += T * VP) {
+      const uint4 gc4 = gq, oc4 = oq;
+      if (o + T * VP < NO) pair_load(o + T * VP);
+      pair_round(o, gc4, oc4);
+    }
   }
   if (M == NFP_COSINE && t < P) {
     const float ip = __builtin_amdgcn_rcpf(fmaxf(nrm, g.eps));
@@ -499,16 +598,17 @@ __global__ void __launch_bounds__(GEMM ? 1024 : kBwdThreads) bwd_fast(const KP g
   }
   __syncthreads();
   NFP_STAMP(2);
+  if constexpr (GEMM) {
+    // The x block is requested HERE: it arrives 2-3 us later whatever the cache level, and the gathers below need
+    // no memory (their table rows were requested at entry).  Requested at entry instead, it delays the pair values:
+    // every wavefront's grad_out / out pieces then queue behind the other wavefronts' x loads (measured 21.5 vs 20.8 us).
+    gemm_x_issue<NHWC>(gxr, g, x16, cb0, cb1 - cb0, t, T);
+    __builtin_amdgcn_sched_barrier(0);
+  }
   // A2: window entry (r, j) = the sum of the pairs that link r with the pixel under slot j, listed by the table
-  for (int e2 = t; e2 < NE; e2 += T) {
-    const uint4 r0 = rw0, r1 = rw1;
-    const uint32_t tqc = tqv;
+  auto gather = [&](int e2, const uint4& r0, const uint4& r1, uint32_t tqc) {
     int r, j;
     const int e = entry_of(e2, r, j);
-    if (e2 + T < NE) {
-      int r_, j_;
-      rows_load(entry_of(e2 + T, r_, j_));
-    }
     float S = 0.f, Dj = 0.f, Dm = 0.f, wv;  // Dj: diagonal term for r, Dm: for the pixel t on the other end
     if (j != K2 / 2) {
       auto take = [&](uint32_t ent) {  // one list entry, predicated (the lists are packed: live entries first)
@@ -579,6 +679,28 @@ __global__ void __launch_bounds__(GEMM ? 1024 : kBwdThreads) bwd_fast(const KP g
     }
     Wt[e] = wv;
     Dt[e] = Dj;
+  };
+  if constexpr (GEMM) {
+#pragma unroll
+    for (int k = 0; k < PRE; ++k)
+      if (t + k * T < NE) gather(t + k * T, prw0[k], prw1[k], ptq[k]);
+  } else {
+    if (t < NE) {
+      if (t + T < NE) {  // the next round's row flies during this round's gathers
+        int r_, j_;
+        rows_load(entry_of(t + T, r_, j_));
+      }
+      gather(t, prw0[0], prw1[0], ptq[0]);
+    }
+    for (int e2 = t + T; e2 < NE; e2 += T) {
+      const uint4 r0 = rw0, r1 = rw1;
+      const uint32_t tqc = tqv;
+      if (e2 + T < NE) {
+        int r_, j_;
+        rows_load(entry_of(e2 + T, r_, j_));
+      }
+      gather(e2, r0, r1, tqc);
+    }
   }
   // (the pair values stay readable until the barrier: with g.early the slab does not overlap them, so the x chunk
   // is committed here, while slower wavefronts still gather)
@@ -601,8 +723,7 @@ __global__ void __launch_bounds__(GEMM ? 1024 : kBwdThreads) bwd_fast(const KP g
   NFP_STAMP(4);
   if constexpr (GEMM) {
     // (the pair values behind the tables are dead: their LDS becomes the GEMM's operand images)
-    bwd_gemm_phase<R, NHWC>(g, Wt, (uint4*)pv4, (const uint16_t*)x + (long long)b * g.sB,
-                            (uint16_t*)gx + (long long)b * g.gB, cb0, cb1, t, T,
+    bwd_gemm_phase<R, NHWC>(g, Wt, gemm_Xt, gemm_Wd, gxr, x16, (uint16_t*)gx + (long long)b * g.gB, cb0, cb1, t, T,
                             POOL ? ggap + (long long)b * g.C : nullptr);
     return;
   }

@@ -634,7 +634,11 @@ int launch_bwd_gemm_t(KP g, const void* x, const void* go, const void* out, cons
   g.G = (g.P * K2 > 2048 ? 1024 : kBwdThreads) / g.P;
   if (g.G < 1) g.G = 1;
   if (g.G > g.Cwg / 4) g.G = g.Cwg / 4;
-  const int T = ((g.P * g.G + 63) / 64) * 64;
+  int T = ((g.P * g.G + 63) / 64) * 64;
+  // phase A of this variant is loop-free (nfp_fast.h): one round of pair values, at most kGemmPre gather rounds
+  const int NJ = Win<R>::RAD >= 2 ? Win<R>::NF + 1 : K2, NE = g.P * NJ, NO = N * g.P;
+  if (NE > nfp::kGemmPre * T || NO > 8 * T) T = 1024;
+  if (NE > nfp::kGemmPre * T || NO > 8 * T) return kNotApplicable;
   g.Cc = g.Cwg;
   const int band = g.R * g.W + g.R, KW = (32 + 2 * band + 30) >> 4;
   const size_t xq = (size_t)((((g.P + 15) >> 4 << 1) + 1) | 1), wq = (size_t)((2 * KW + 1) | 1);
