@@ -221,17 +221,24 @@ __device__ __forceinline__ void gemm_fetch_row(uint4& v, const KP& g, const uint
   const uint2 hi = 8 * gs + 4 < g.P ? *(const uint2*)(src + 4) : make_uint2(0, 0);  // (P % 4 == 0: a whole half or none)
   v = make_uint4(lo.x, lo.y, hi.x, hi.y);
 }
+// part 0, 1, 2 of the request (3 + 3 + 2 of the eight NHWC loads, 2 + 1 + 1 of the four NCHW pieces): one part in
+// front of each gather round, so that no wavefront sits on a full load queue while it could be gathering
 template <bool NHWC>
-__device__ __forceinline__ void gemm_x_issue(GemmX<NHWC>& s, const KP& g, const uint16_t* xb, int cb0, int ncw, int t, int T) {
+__device__ __forceinline__ void gemm_x_issue(GemmX<NHWC>& s, const KP& g, const uint16_t* xb, int cb0, int ncw, int t, int T,
+                                             int part) {
   const int P = g.P, pg = (P + 7) >> 3;
   if constexpr (NHWC) {
     const int co4 = ncw >> 5, nblk = co4 * ((pg + 15) >> 4);
     int k, gq;
     gemm_block_of(min(__builtin_amdgcn_readfirstlane(t >> 6), nblk - 1), co4, t & 63, k, gq);
-    gemm_fetch8(s.v, g, xb, cb0, k, min(gq, pg));
+    gq = min(gq, pg);
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (u / 3 == part) s.v[u] = *(const uint4*)(xb + (long long)min(8 * gq + u, P - 1) * g.C + cb0 + 8 * k);
   } else if ((P & 3) == 0) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) gemm_fetch_row(s.v[u], g, xb, cb0, pg, min(t + u * T, ncw * pg - 1));
+    for (int u = 0; u < 4; ++u)
+      if ((u == 0 ? 0 : u - 1) == part) gemm_fetch_row(s.v[u], g, xb, cb0, pg, min(t + u * T, ncw * pg - 1));
   }
 }
 template <bool NHWC>
@@ -598,13 +605,7 @@ __global__ void __launch_bounds__(GEMM ? 1024 : kBwdThreads) bwd_fast(const KP g
   }
   __syncthreads();
   NFP_STAMP(2);
-  if constexpr (GEMM) {
-    // The x block is requested HERE: it arrives 2-3 us later whatever the cache level, and the gathers below need
-    // no memory (their table rows were requested at entry).  Requested at entry instead, it delays the pair values:
-    // every wavefront's grad_out / out pieces then queue behind the other wavefronts' x loads (measured 21.5 vs 20.8 us).
-    gemm_x_issue<NHWC>(gxr, g, x16, cb0, cb1 - cb0, t, T);
-    __builtin_amdgcn_sched_barrier(0);
-  }
+
   // A2: window entry (r, j) = the sum of the pairs that link r with the pixel under slot j, listed by the table
   auto gather = [&](int e2, const uint4& r0, const uint4& r1, uint32_t tqc) {
     int r, j;
@@ -681,9 +682,18 @@ __global__ void __launch_bounds__(GEMM ? 1024 : kBwdThreads) bwd_fast(const KP g
     Dt[e] = Dj;
   };
   if constexpr (GEMM) {
+    // The x block is requested HERE, a part in front of each gather round: it arrives 2-3 us later whatever the
+    // cache level, and the gathers need no memory (their table rows were requested at entry).  Requested at entry
+    // instead, it delays the pair values: every wavefront's grad_out / out pieces then queue behind the other
+    // wavefronts' x loads (measured 21.5 vs 20.8 us).
 #pragma unroll
-    for (int k = 0; k < PRE; ++k)
+    for (int k = 0; k < PRE; ++k) {
+      if (k < 3) {
+        gemm_x_issue<NHWC>(gxr, g, x16, cb0, cb1 - cb0, t, T, k);
+        __builtin_amdgcn_sched_barrier(0);
+      }
       if (t + k * T < NE) gather(t + k * T, prw0[k], prw1[k], ptq[k]);
+    }
   } else {
     if (t < NE) {
       if (t + T < NE) {  // the next round's row flies during this round's gathers
