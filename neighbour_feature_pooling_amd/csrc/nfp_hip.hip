@@ -559,8 +559,10 @@ int launch_bwd_fast_t(KP g, const void* x, const void* go, const void* out, cons
 #endif
   int S = (NFP_BWD_WGS + g.B - 1) / g.B;  // channel blocks per image so that >= NFP_BWD_WGS workgroups exist
   // ... and twice as many while a workgroup's block stays large ([256,960,7,7]: 22.9 -> 21.5 us, [256,192,14,14]: 21.3 ->
-  // 20.2 us; not [256,512,7,7]: 13.8 -> 14.0 us): phase A is repeated per block, the streaming part is what splits
-  if ((long long)g.C * g.P / S >= 32768 && (long long)g.B * S < 2 * NFP_BWD_WGS) S = (2 * NFP_BWD_WGS + g.B - 1) / g.B;
+  // 20.2 us; not [256,512,7,7]: 13.8 -> 14.0 us): phase A is repeated per block, the streaming part is what splits.
+  // k = 3 only: a 5x5 window's phase A is a third of the kernel ([256,192,14,14] L2 k = 5 f32: 41.0 -> 49.6 us split)
+  if (K2 <= 9 && (long long)g.C * g.P / S >= 32768 && (long long)g.B * S < 2 * NFP_BWD_WGS)
+    S = (2 * NFP_BWD_WGS + g.B - 1) / g.B;
   if (S > g.C / 4) S = g.C / 4;
   if (S < 1) S = 1;
   g.Cwg = round4((g.C + S - 1) / S);
