@@ -65,6 +65,11 @@ def test_plan_does_not_launch_or_disturb_last_variant(lib):
      "fwd_gram<R2,l2,bf16,nhwc>", "bwd_fast<R2,l2,bf16,nhwc,mfma>"),                                    # ViT tokens: matrix cores
     (dict(shape=(256, 512, 7, 7), dtype=_abi.BF16), "fwd_gram<R1,cos,bf16,nchw>", "bwd_fast<R1,cos,bf16,nchw>"),   # odd rows, no channel split
     (dict(shape=(64, 512, 7, 7), dtype=_abi.BF16), "fwd_gram<R1,cos,bf16,nchw>", "bwd_fast<R1,cos,bf16,nchw,mfma>"),
+    # the matrix-core backward's loop-free phase A: at most four gather rounds of its (up to 1024) threads
+    (dict(shape=(4, 64, 16, 16), R=2, measure="norm", dtype=_abi.BF16, channels_last=True),
+     "fwd_gram<R2,l2,bf16,nhwc>", "bwd_fast<R2,l2,bf16,nhwc,mfma>"),                                    # 256 x 13 = 3328 entries
+    (dict(shape=(4, 64, 18, 18), R=2, measure="norm", dtype=_abi.BF16, channels_last=True),
+     "fwd_gram<R2,l2,bf16,nhwc>", "bwd_fast<R2,l2,bf16,nhwc>"),                                         # 324 x 13 = 4212: vector kernel
     (dict(shape=(64, 512, 7, 7), measure="norm", p=1.0), "fwd_pairs", "bwd_gather"),                    # reference default p
     (dict(shape=(64, 512, 7, 7), pad=0), "fwd_pairs", "bwd_gather"),                                    # pad != R
     (dict(shape=(64, 512, 7, 7), stride=2), "fwd_pairs", "bwd_gather"),

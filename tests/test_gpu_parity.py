@@ -711,6 +711,8 @@ def test_random_geometry_stress(dev, monkeypatch):
     (5, 192, 14, 14, 2, "norm", "reflect", "nchw"),          # NCHW bf16: transposed into the same LDS image
     (5, 512, 7, 7, 1, "cosine", "reflect", "nchw"),
     (5, 48, 6, 5, 2, "cosine", "zeros", "nchw"),
+    (260, 512, 7, 7, 1, "cosine", "reflect", "randn"),      # one workgroup per image: more Xt blocks than wavefronts
+    (260, 256, 8, 8, 1, "norm", "reflect", "nchw"),         # ... and more NCHW pieces than four per thread
 ])
 def test_matrix_core_forward_bf16(B, C, H, W, R, meas, mode, kind, dev, monkeypatch):
     """fwd_gram (nfp_mfma.h): banded Gram matrix on v_mfma_f32_32x32x16_bf16.  Same bf16 inputs, f32 accumulation:
