@@ -393,16 +393,31 @@ __device__ __forceinline__ void bwd_gemm_phase(const KP& g, const float* Wt, uin
           acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xv, acc, 0, 0, 0);
         }
       }
-      if (NHWC) {            // D[row = channel][col = pixel]: 4 consecutive channels of pixel r per group
+      if (NHWC) {            // D[row = channel][col = pixel]: 4 consecutive channels of pixel r per register group
+        // Lane (r, h) holds channels 4h + {0-3, 8-11, 16-19, 24-27} of pixel r: four 8-byte pieces, and four store
+        // instructions of 64 scattered pieces each were the longest part of a round (the texture path takes an address
+        // per lane: 12 tiles x 4 x 64 per round).  v_permlane32_swap trades the packed groups between lanes r and
+        // r + 32, so that each holds 8 consecutive channels twice: two 16-byte stores.
         const int pp = 32 * it + r;
-        if (pp < P) {
+        uint32_t pk[8];
 #pragma unroll
-          for (int gq = 0; gq < 4; ++gq) {
-            uint2 w;
-            w.x = f32_to_bf16x2(acc[4 * gq], acc[4 * gq + 1]);
-            w.y = f32_to_bf16x2(acc[4 * gq + 2], acc[4 * gq + 3]);
-            *(uint2*)(gxb + (long long)pp * C + cb0 + 32 * ct + 8 * gq + 4 * h) = w;
+        for (int gq = 0; gq < 4; ++gq) {
+          pk[2 * gq] = f32_to_bf16x2(acc[4 * gq], acc[4 * gq + 1]);
+          pk[2 * gq + 1] = f32_to_bf16x2(acc[4 * gq + 2], acc[4 * gq + 3]);
+        }
+#pragma unroll
+        for (int gp = 0; gp < 4; gp += 2) {   // (groups gp, gp + 1): the upper lanes' gp <-> the lower lanes' gp + 1
+#pragma unroll
+          for (int d = 0; d < 2; ++d) {
+            const auto sw = __builtin_amdgcn_permlane32_swap(pk[2 * gp + d], pk[2 * gp + 2 + d], false, false);
+            pk[2 * gp + d] = sw[0];
+            pk[2 * gp + 2 + d] = sw[1];
           }
+        }
+        if (pp < P) {
+          uint16_t* dst = gxb + (long long)pp * C + cb0 + 32 * ct + 8 * h;
+          *(uint4*)dst = make_uint4(pk[0], pk[1], pk[2], pk[3]);          // channels 8h .. 8h + 7
+          *(uint4*)(dst + 16) = make_uint4(pk[4], pk[5], pk[6], pk[7]);   // channels 16 + 8h .. 16 + 8h + 7
         }
       } else if ((P & 3) == 0) {  // D[row = pixel][col = channel]: 4 consecutive pixels of channel r per group
         uint16_t* dst = gxb + (long long)(cb0 + 32 * ct + r) * P + 32 * it + 4 * h;

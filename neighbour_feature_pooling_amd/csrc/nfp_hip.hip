@@ -622,7 +622,8 @@ int launch_bwd_gemm_t(KP g, const void* x, const void* go, const void* out, cons
                       hipStream_t st, const float* ggap = nullptr, const float* gnfpm = nullptr) {
   constexpr int N = Win<R>::N, K2 = Win<R>::K2;
   if (!mfma_enabled() || g.dtype != NFP_BF16 || (g.C & 31)) return kNotApplicable;
-  if (NHWC && (((uintptr_t)x & 15) || ((g.sB * 2) & 15))) return kNotApplicable;  // 16-byte staging loads
+  if (NHWC && (((uintptr_t)x & 15) || ((g.sB * 2) & 15) || ((uintptr_t)gx & 15) || ((g.gB * 2) & 15)))
+    return kNotApplicable;  // 16-byte staging loads and grad_x stores
   int S = (NFP_BWD_WGS + g.B - 1) / g.B;  // channel blocks per image, whole 32-channel tiles each
   if (S > g.C / 32) S = g.C / 32;
   if (S < 1) S = 1;
