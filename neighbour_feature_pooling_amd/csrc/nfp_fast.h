@@ -229,12 +229,16 @@ __device__ __forceinline__ void gemm_x_issue(GemmX<NHWC>& s, const KP& g, const 
   const int P = g.P, pg = (P + 7) >> 3;
   if constexpr (NHWC) {
     const int co4 = ncw >> 5, nblk = co4 * ((pg + 15) >> 4);
-    int k, gq;
-    gemm_block_of(min(__builtin_amdgcn_readfirstlane(t >> 6), nblk - 1), co4, t & 63, k, gq);
-    gq = min(gq, pg);
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    if (wave < nblk) {  // (wavefronts past the last block, and lanes past the last pixel group, request nothing: the
+      int k, gq;        // texture path takes every address it is given)
+      gemm_block_of(wave, co4, t & 63, k, gq);
+      if (gq < pg) {
 #pragma unroll
-    for (int u = 0; u < 8; ++u)
-      if (u / 3 == part) s.v[u] = *(const uint4*)(xb + (long long)min(8 * gq + u, P - 1) * g.C + cb0 + 8 * k);
+        for (int u = 0; u < 8; ++u)
+          if (u / 3 == part) s.v[u] = *(const uint4*)(xb + (long long)min(8 * gq + u, P - 1) * g.C + cb0 + 8 * k);
+      }
+    }
   } else if ((P & 3) == 0) {
 #pragma unroll
     for (int u = 0; u < 4; ++u)
