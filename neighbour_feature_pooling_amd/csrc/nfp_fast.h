@@ -576,7 +576,13 @@ __global__ void __launch_bounds__(GEMM ? 1024 : kBwdThreads) bwd_fast(const KP g
       stage_store_ovl(st, slab, g, ncq, t, T);
   };
   GemmX<NHWC> gxr;
-  if constexpr (!GEMM) x_issue(cb0, min(g.Cc, cb1 - cb0) >> 2);
+#ifndef NFP_VEC_X_LATE
+#define NFP_VEC_X_LATE 1   // 1 = k = 5 vector kernels request their first x chunk after the pair values (their gather
+                           // rounds hide it: [64,512,7,7] k = 5 10.97 -> 10.68 us, [256,192,14,14] 42.0 -> 41.3; k = 3
+                           // measures the same either way and keeps the request at entry), 0 = none, 2 = all do
+#endif
+  constexpr bool X_LATE = !GEMM && (NFP_VEC_X_LATE == 2 || (NFP_VEC_X_LATE == 1 && Win<R>::RAD >= 2));
+  if constexpr (!GEMM && !X_LATE) x_issue(cb0, min(g.Cc, cb1 - cb0) >> 2);
   // nothing that consumes a loaded value may be scheduled above this line (hipcc otherwise hoists consumers into
   // the load sequence and stalls the remaining loads behind a vmcnt wait)
   __builtin_amdgcn_sched_barrier(0);
@@ -624,6 +630,10 @@ __global__ void __launch_bounds__(GEMM ? 1024 : kBwdThreads) bwd_fast(const KP g
   }
   __syncthreads();
   NFP_STAMP(2);
+  if constexpr (X_LATE) {
+    x_issue(cb0, min(g.Cc, cb1 - cb0) >> 2);
+    __builtin_amdgcn_sched_barrier(0);
+  }
 
   // A2: window entry (r, j) = the sum of the pairs that link r with the pixel under slot j, listed by the table
   auto gather = [&](int e2, const uint4& r0, const uint4& r1, uint32_t tqc) {
