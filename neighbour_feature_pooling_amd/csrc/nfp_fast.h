@@ -314,7 +314,8 @@ __device__ __forceinline__ void gemm_stage_x(const KP& g, uint4* Xt, const uint1
   }
 }
 
-// gg: grad of the pooled channel means of this image (fused pooling tail) or null: every grad_x[c][p] also gets gg[c]/P.
+// gg: (fused pooling tail) this workgroup's channels of grad(GAP(x)) / P, staged in LDS by bwd_fast, or null: every
+// grad_x[c][p] also gets gg[c - cb0].  (Read from global memory in the tile loop they cost 4 of 22 us at config 5.)
 // Xt, Wd: the two operand images in LDS (placed by bwd_fast); pre: the share of x requested at kernel entry.
 template <int R, bool NHWC>
 __device__ __forceinline__ void bwd_gemm_phase(const KP& g, const float* Wt, uint4* Xt, uint4* Wd, GemmX<NHWC>& pre,
@@ -384,7 +385,7 @@ __device__ __forceinline__ void bwd_gemm_phase(const KP& g, const float* Wt, uin
 #pragma unroll
       for (int e = 0; e < 16; ++e) {  // element e of lane (r, h) is D[row (e & 3) + 8 (e >> 2) + 4 h][column r]
         const int ch = 32 * ct + (rows_are_channels ? (e & 3) + 8 * (e >> 2) + 4 * h : r);
-        acc[e] = gg != nullptr ? gg[cb0 + ch] * g.invP : 0.f;
+        acc[e] = gg != nullptr ? gg[ch] : 0.f;
       }
       for (int s = 0; s < ks; ++s) {
         const bf16x8 wh = __builtin_bit_cast(bf16x8, Wh[2 * s]), wl = __builtin_bit_cast(bf16x8, Wl[2 * s]);
@@ -486,6 +487,18 @@ __global__ void __launch_bounds__(GEMM ? 1024 : kBwdThreads) bwd_fast(const KP g
   uint4* gemm_Xt = (uint4*)pv4;
   uint4* gemm_Wd = gemm_Xt + (long long)(cb1 - cb0) * gemm_xq(P);
   const uint16_t* x16 = (const uint16_t*)x + (long long)b * g.sB;
+  // fused pooling tail, matrix-core variant: grad(GAP(x)) / P of this workgroup's channels goes to LDS behind Wd (read
+  // from global memory in the tile loop it cost 4 of 22 us at config 5).  Two values per thread are requested here.
+  // (The vector kernel keeps its 16-byte global loads in the channel loop: staged the same way it measured 7.3 vs 6.7 us.)
+  float* gg_s = nullptr;
+  float ggv0 = 0.f, ggv1 = 0.f;
+  if constexpr (POOL && GEMM) {
+    const int ncw = cb1 - cb0;
+    const int band = Win<R>::RAD * g.W + Win<R>::RAD, KW = (32 + 2 * band + 30) >> 4;
+    gg_s = (float*)(gemm_Wd + (long long)g.Tc * 2 * 32 * odd_up(2 * KW + 1));
+    if (t < ncw) ggv0 = ggap[(long long)b * g.C + cb0 + t];
+    if (t + T < ncw) ggv1 = ggap[(long long)b * g.C + cb0 + t + T];
+  }
   const int gl = fast_div(t, g.invP), p = t - gl * P;
   const bool active = gl < g.G;
   constexpr int ES = BF ? 2 : 4;
@@ -591,10 +604,20 @@ __global__ void __launch_bounds__(GEMM ? 1024 : kBwdThreads) bwd_fast(const KP g
   // (first round outside the loop: hipcc's wait-count pass is exact in straight-line code only, and a wait that
   // also covers the x block just requested would put its whole latency in front of phase A)
   auto pair_round = [&](int o, const uint4& gc4, const uint4& oc4) {
+    // fused pooling tail: grad_out[n][p] = grad(GAP(NFP))[n] / P for every p; a thread's VP consecutive pairs lie in at
+    // most two maps when P >= VP: two loads instead of one per pair
+    int n0 = 0;
+    float gn0 = 0.f, gn1 = 0.f;
+    if constexpr (POOL) {
+      n0 = fdivi(o, P);
+      gn0 = gnfpm[(long long)b * N + n0] * g.invP;
+      gn1 = gnfpm[(long long)b * N + min(n0 + 1, N - 1)] * g.invP;
+    }
 #pragma unroll
     for (int k = 0; k < VP; ++k) {
       const float oc = pair_value(oc4, k);
-      const float gc = POOL ? gnfpm[(long long)b * N + fdivi(o + k, P)] * g.invP : pair_value(gc4, k);
+      const float gc = !POOL ? pair_value(gc4, k)
+                       : (P >= VP ? ((o + k) >= (n0 + 1) * P ? gn1 : gn0) : gnfpm[(long long)b * N + fdivi(o + k, P)] * g.invP);
       if (M == NFP_COSINE) {
         const float s = g.similarity ? oc : 1.f - oc;
         const float sg = g.similarity ? gc : -gc;
@@ -627,6 +650,12 @@ __global__ void __launch_bounds__(GEMM ? 1024 : kBwdThreads) bwd_fast(const KP g
   if constexpr (SYM) {  // slots before the centre whose pixel lies outside the image keep this 0 (Wt and Dt are adjacent)
     for (int i = t; i < (2 * P * K2) >> 2; i += T) ((float4*)Wt)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (t < ((2 * P * K2) & 3)) Wt[((2 * P * K2) & ~3) + t] = 0.f;
+  }
+  if constexpr (POOL && GEMM) {
+    const int ncw = cb1 - cb0;
+    if (t < ncw) gg_s[t] = ggv0 * g.invP;
+    if (t + T < ncw) gg_s[t + T] = ggv1 * g.invP;
+    for (int i = t + 2 * T; i < ncw; i += T) gg_s[i] = ggap[(long long)b * g.C + cb0 + i] * g.invP;  // (more than 2T channels)
   }
   __syncthreads();
   NFP_STAMP(2);
@@ -763,7 +792,7 @@ __global__ void __launch_bounds__(GEMM ? 1024 : kBwdThreads) bwd_fast(const KP g
   if constexpr (GEMM) {
     // (the pair values behind the tables are dead: their LDS becomes the GEMM's operand images)
     bwd_gemm_phase<R, NHWC>(g, Wt, gemm_Xt, gemm_Wd, gxr, x16, (uint16_t*)gx + (long long)b * g.gB, cb0, cb1, t, T,
-                            POOL ? ggap + (long long)b * g.C : nullptr);
+                            POOL ? gg_s : nullptr);
     return;
   }
   float w[K2];

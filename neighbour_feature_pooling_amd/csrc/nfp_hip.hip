@@ -648,12 +648,13 @@ int launch_bwd_gemm_t(KP g, const void* x, const void* go, const void* out, cons
   // row tiles whose densified weights sit in LDS together (fewer rounds of zero / scatter / barrier): all that fit
   const int nt = (g.P + 31) / 32;
   const size_t xt = (size_t)g.Cwg * xq * 16, wd1 = (size_t)2 * 32 * wq * 16, fixed = bwd_fixed_bytes(g, K2);
-  int rt = fixed + xt < (size_t)kLdsMax ? (int)(((size_t)kLdsMax - fixed - xt) / wd1) : 0;
+  const size_t ggb = POOL ? (size_t)g.Cwg * 4 : 0;   // grad(GAP(x)) of the block, staged behind Wd
+  int rt = fixed + xt + ggb < (size_t)kLdsMax ? (int)(((size_t)kLdsMax - fixed - xt - ggb) / wd1) : 0;
   rt = std::min(rt, nt);
   if (rt >= 2 && rt < nt) rt = (nt + ((nt + rt - 1) / rt) - 1) / ((nt + rt - 1) / rt);  // even rounds
   if (rt < std::min(2, nt)) return kNotApplicable;
   g.Tc = rt;
-  const size_t images = xt + (size_t)rt * wd1;
+  const size_t images = xt + (size_t)rt * wd1 + ggb;
   const size_t lds = fixed + std::max(bwd_pair_bytes(g, M, N), images);
   g.early = 0;
   if (lds > (size_t)kLdsMax) return kNotApplicable;
