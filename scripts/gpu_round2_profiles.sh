@@ -2,6 +2,9 @@
 # Round-2 evidence in one gpurun call: rocprofv3 kernel stats + FETCH/WRITE_SIZE passes for the headline, config 5 and
 # the saturating batch; shape sweep; 1-GPU train steps; the default bench line.  Copy what it leaves under
 # gpurun_out/ into profiles/ (see DESIGN.md section 5 for the file names).
+# The other round-2 files come from their own scripts: r02_j  scripts/gpu_matrix_core_ab.sh (after scripts/ab_flags.py
+# --build and a library of the "before" commit in neighbour_feature_pooling_amd/ab/), r02_k  scripts/gpu_train_share.sh,
+# r02_l  scripts/gpu_fused_callers.py, r02_i  scripts/ab_flags.py with -DNFP_BWD_STORE_AUX variants.
 set -u
 rm -f gpurun_out/traffic_workloads.json
 C5="--batch 256 --channels 192 --size 14 --radius 2 --measure norm --dtype bf16 --layout nhwc"
