@@ -3,6 +3,10 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
 
+`--gpus N` with N > 1 starts N ranks itself (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ...` as a
+child process, one rank per GPU over RCCL); under an external launcher (WORLD_SIZE / RANK in the environment) it runs
+as the rank it is told to be and checks that WORLD_SIZE equals N.
+
 A step = one NFPPooling forward + one backward (given grad_out) over one batch of synthetic feature maps
 already resident in HBM, through the product path (nn.Module -> autograd -> C ABI -> HIP kernels).
 Workload at every N: BASELINE.json configs[1], NFP(cosine, k=3) on [B=64, C=512, 7x7] fp32 per GPU (weak
@@ -56,6 +60,8 @@ def parse(argv=None):
                     "live-traffic legs: every NFP launch of the process then belongs to the rotating leg, so a rocprofv3 "
                     "--kernel-trace --stats summary of the run averages exactly the launches `roofline` is quoted on")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)  # run under rocprofv3 --pmc by bench.py itself
+    ap.add_argument("--print-launch", action="store_true", help="with --gpus N > 1 and no launcher: print the "
+                    "torch.distributed.run command the N ranks would be started with, and exit")
     return ap.parse_args(argv)
 
 
@@ -383,13 +389,22 @@ def main():
     args = parse()
     if args.pmc_child:
         return pmc_child(args)
+    backend = os.environ.get("NFP_BENCH_BACKEND", "nccl")
+    from neighbour_feature_pooling_amd import parallel
+    if args.gpus > 1 and not parallel.launched_by_torchrun():
+        # `python bench.py --gpus N`: this process becomes the launcher of N ranks (one per GPU) and only relays their
+        # exit code — it has made no GPU call, and the ranks are children, never an exec of this process
+        argv = [a for a in sys.argv[1:] if a != "--print-launch"]
+        sys.exit(parallel.self_launch(args.gpus, os.path.abspath(__file__), argv, backend=backend,
+                                      dry_run=args.print_launch))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     # NFP_BENCH_BACKEND=gloo rehearses the N>1 path with several ranks sharing one GPU (RCCL refuses that)
-    backend = os.environ.get("NFP_BENCH_BACKEND", "nccl")
     local = local % torch.cuda.device_count() if backend == "gloo" else local
     if world > 1:
         import torch.distributed as dist

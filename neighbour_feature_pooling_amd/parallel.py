@@ -5,6 +5,11 @@ path has NO collective.  The only cross-rank traffic is what a caller asks for e
 `gather_batch` (to reassemble an output for checking) and `max_over_ranks` (bench timing).
 With torch.distributed backend "nccl" these run over RCCL/xGMI; tests use "gloo" on CPU.
 """
+import os
+import socket
+import subprocess
+import sys
+
 import torch
 import torch.distributed as dist
 
@@ -54,3 +59,42 @@ def max_over_ranks(value, device=None):
     t = torch.tensor([float(value)], dtype=torch.float64, device=device or "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return t.item()
+
+
+# ---- one process per GPU, started by the program itself --------------------------------------------------------
+# `python bench.py --gpus N` (and `python -m neighbour_feature_pooling_amd.train --gpus N`) must run N ranks with no
+# launcher on the command line.  The parent starts `python -m torch.distributed.run` as a CHILD process and relays its
+# exit code; it never touches the GPU itself (importing torch does not initialise it, and neither does
+# torch.cuda.device_count() on this image), and nothing is exec'ed from a process that has.
+
+def launched_by_torchrun():
+    return "WORLD_SIZE" in os.environ and "RANK" in os.environ
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch_command(n, target, argv, port=None):
+    """The child command for `n` ranks of `target` — a script path, or ("-m", "package.module")."""
+    tgt = list(target) if isinstance(target, (tuple, list)) else [target]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+            "--master-addr=127.0.0.1", f"--master-port={port or free_port()}", *tgt, *argv]
+
+
+def self_launch(n, target, argv, backend="nccl", dry_run=False):
+    """Start `n` ranks of `target argv` and return their exit code (0 only if every rank succeeded).  With the RCCL
+    backend every rank needs a GPU of its own: fails loudly otherwise.  dry_run: print the command, start nothing."""
+    cmd = self_launch_command(n, target, argv)
+    if dry_run:
+        print(" ".join(cmd), flush=True)
+        return 0
+    if backend == "nccl":
+        have = torch.cuda.device_count()
+        if n > have:
+            raise SystemExit(f"--gpus {n}: this node has {have} GPU(s); RCCL needs one per rank "
+                             f"(a gloo rehearsal may share them)")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.run(cmd, env=env).returncode

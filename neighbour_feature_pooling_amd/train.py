@@ -7,8 +7,8 @@ the reference lacks: one process per GPU, DistributedDataParallel with bucketed 
 over RCCL/xGMI (backend "nccl" on ROCm; "gloo" on CPU for tests).  NFP itself has no parameters, so
 it contributes nothing to the all-reduce and needs no find_unused_parameters.
 
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \\
-        -m neighbour_feature_pooling_amd.train --model resnet18 --batch 256 --image 224 --steps 20
+    python -m neighbour_feature_pooling_amd.train --gpus 8 --model resnet18 --batch 256 --image 224 --steps 20
+(starts the 8 ranks itself; or under `python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 ...`)
 """
 import argparse
 import json
@@ -70,8 +70,17 @@ def main():
     ap.add_argument("--cpu", action="store_true", help="gloo on CPU (plumbing test)")
     ap.add_argument("--backend", default=None, help="override the process-group backend (gloo lets several "
                     "ranks share one GPU for rehearsal; RCCL refuses that)")
+    ap.add_argument("--gpus", type=int, default=1, help="N > 1 without a launcher: start N ranks (one per GPU)")
+    ap.add_argument("--print-launch", action="store_true", help="with --gpus N: print the launch command and exit")
     a = ap.parse_args()
 
+    from . import parallel
+    if a.gpus > 1 and not parallel.launched_by_torchrun():
+        import sys
+        argv = [v for v in sys.argv[1:] if v != "--print-launch"]
+        raise SystemExit(parallel.self_launch(a.gpus, ("-m", __spec__.name if __spec__ else "neighbour_feature_pooling_amd.train"),
+                                              argv, backend=a.backend or ("gloo" if a.cpu else "nccl"),
+                                              dry_run=a.print_launch))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
