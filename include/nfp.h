@@ -143,8 +143,9 @@ int nfp_backward(const nfp_desc* d, const void* x, const void* grad_out, const v
  *   gap  [B,C] f32 = AdaptiveAvgPool2d(1)(x)                          NFP_Pooling.py:27
  *   nfpm [B,N] f32 = adaptive_avg_pool2d(NFPPooling(x), 1)            NFP_Pooling.py:29-31
  * out_map [B,N,Ho,Wo] (dtype of x) is also written: the backward needs it, callers may ignore it.
- * Served only where nfp_pool_supported(d) != 0 (hot-path geometry, NCHW float32); otherwise compose
- * nfp_forward with ordinary pooling.
+ * Served only where nfp_pool_supported(d) != 0 — cosine / L2 on "same" maps (stride 1, padding = R) with the descriptor's
+ * workspace set, NCHW or channels-last, float32 or bf16; the answer is a dry run of both launchers, so a 1 means both
+ * nfp_pool_forward and nfp_pool_backward will launch.  Otherwise compose nfp_forward with ordinary pooling.
  */
 int nfp_pool_supported(const nfp_desc* d);
 int nfp_pool_forward(const nfp_desc* d, const void* x, float* gap, float* nfpm, void* out_map, float* saved,
@@ -162,10 +163,12 @@ uint64_t nfp_launch_count(void);
  * copied into a buffer of the calling thread. */
 const char* nfp_last_variant(void);
 
-/* Telemetry: the NEXT forward / backward kernel this process launches is bracketed by the two hipEvent_t
+/* Telemetry: the NEXT forward / backward kernel this PROCESS launches — from whichever thread: autograd runs the
+ * backward on a thread of its own, so the arming cannot be per calling thread — is bracketed by the two hipEvent_t
  * (hipExtLaunchKernel: recorded at the kernel's own start and end on the device, as a profiler's kernel trace
  * would) — per-kernel durations without a profiler and without inter-kernel gaps.  One shot; pass NULLs to
- * disarm.  bench.py quotes its roofline on these. */
+ * disarm.  SINGLE-LAUNCHER USE ONLY: while it is armed no second thread may enqueue NFP work, or the events bracket
+ * that thread's kernel instead.  bench.py's *_eager_event_us figures come from here (one launch in flight at a time). */
 void nfp_time_next_launch(void* start_event, void* stop_event);
 
 /* Test hook: re-read the NFP_* A/B switches (NFP_FORCE_GENERIC, NFP_FWD_SCALAR,

@@ -26,6 +26,19 @@ constexpr int kBandT = NFP_BAND_T;  // most threads per workgroup: pixels of the
 constexpr int kBandRB = 3;   // NCHW staging: 4-pixel x 4-channel blocks per thread per chunk
 constexpr int kBandRN = 6;   // channels-last staging: slots per thread per chunk
 
+// Slots per slab row (one channel quad) of a band whose staged pixels span `span` slots (a multiple of 4).  The channel
+// sums read one ds_read_b128 per (quad, direction) with thread t = pixel * G + group: the hardware serves 16 lanes per
+// cycle (lanes {0-3,12-15,20-27}, ...), i.e. 16/G pixels x G quads when G < 16, and those 16 slots must fall into 16
+// different 16-byte bank columns.  G >= 32: the 16 lanes are 16 quads of ONE pixel -> any odd stride.  G = 16: 8 quads
+// of a pixel + 8 of the next -> stride = 2 mod 4.  G = 8, 4: four quads each of four consecutive pixels -> stride = 4
+// mod 8.  (Round 2 used an odd stride for every G: at [4096,512,7,7], G = 8, 52 % of the LDS-active cycles were bank
+// conflicts — profiles/r03_b_fwd_band_pmc_baseline.csv; tools/lds_bank_sim_band.py reproduces 9.0 vs 4.8 cycles per read.)
+__host__ __device__ inline int band_row_slots(int span, int lg) {
+  if (lg >= 5 || lg <= 1) return span | 1;
+  if (lg == 4) return span + 2;
+  return (span & 7) == 4 ? span : span + 4;
+}
+
 template <int R>
 struct FoffQ {
   static constexpr int v = ((Win<R>::NF + 7) & ~7) / 8;  // 16-byte pieces of a pixel's foff row (ws_layout: FR)
@@ -55,9 +68,8 @@ __global__ void __launch_bounds__(1024) fwd_band(const KP g, const void* __restr
   const int y0 = band * rb, y1 = min(g.H, y0 + rb), ye = min(g.H, y1 + g.R);
   const int p0 = y0 * W, po = y1 * W, pe = ye * W, Ps = pe - p0;
   const int base = p0 & ~7;                          // slot origin of the band's slab rows
-  const int Ppb = (((pe + 3) & ~3) - base) | 1;      // slots per slab row (one channel quad); odd: the G adjacent lanes
-                                                     // of a pixel read G different rows at one slot — distinct banks
   const int G = g.G, lg = g.Tc;                      // channel groups (power of two), log2
+  const int Ppb = band_row_slots(((pe + 3) & ~3) - base, lg);   // slots per slab row (one channel quad)
   const int gl = t & (G - 1), lpc = t >> lg;         // channel-sum map
   const bool active = lpc < Ps;
   const int lp = min(lpc, Ps - 1), p = p0 + lp;
@@ -120,9 +132,11 @@ __global__ void __launch_bounds__(1024) fwd_band(const KP g, const void* __restr
           const int cq = fdivi(i, NQb), pq = q0 + i - cq * NQb;
           const int ps = min(4 * pq, P - 4);
           float4* d = slab + cq * Ppb - base;
-          d[swz(ps)] = make_float4(blk[r][0].x, blk[r][1].x, blk[r][2].x, blk[r][3].x);
-          d[swz(ps + 1)] = make_float4(blk[r][0].y, blk[r][1].y, blk[r][2].y, blk[r][3].y);
-          d[swz(ps + 2)] = make_float4(blk[r][0].z, blk[r][1].z, blk[r][2].z, blk[r][3].z);
+          // (the overlapped last block of an image with P % 4 != 0 may start below the band's slot origin: those pixels
+          // belong to the band above and have no slot here)
+          if (ps >= base) d[swz(ps)] = make_float4(blk[r][0].x, blk[r][1].x, blk[r][2].x, blk[r][3].x);
+          if (ps + 1 >= base) d[swz(ps + 1)] = make_float4(blk[r][0].y, blk[r][1].y, blk[r][2].y, blk[r][3].y);
+          if (ps + 2 >= base) d[swz(ps + 2)] = make_float4(blk[r][0].z, blk[r][1].z, blk[r][2].z, blk[r][3].z);
           d[swz(ps + 3)] = make_float4(blk[r][0].w, blk[r][1].w, blk[r][2].w, blk[r][3].w);
         }
       }

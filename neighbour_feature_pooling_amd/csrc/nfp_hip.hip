@@ -513,7 +513,8 @@ int launch_fwd_band_t(KP g, const void* x, void* out, float* saved, hipStream_t 
   g.G = 1 << lg;
   g.Tc = lg;
   const int T = ((g.G * psm + 63) / 64) * 64;
-  const int nqb = (psm + 3) / 4 + 1, ppb = (psm + 3 + 8) | 1;   // blocks / slots per slab row, alignment slack included
+  const int nqb = (psm + 3) / 4 + 1, ppb = ((psm + 3 + 8) & ~3) + 4;   // blocks / slots per slab row, alignment slack and
+                                                                       // the bank padding of band_row_slots included
   // up to one workgroup per CU the whole band is staged at once; beyond that, half-size slabs let two workgroups share a
   // CU and overlap each other's load / sum phases ([4096,512,7,7]: 91 vs 118 us)
   const int budget = (long long)g.B * nb > 256 ? NFP_FWD_SLAB_KB * 512 : NFP_FWD_SLAB_KB * 1024;
@@ -996,15 +997,49 @@ int nfp_plan(const nfp_desc* d, int32_t backward, char* buf, int32_t buflen) {
 }
 
 // ---- fused nfp_pooling tail (models/NFP_Pooling.py:27-31) ----------------------------------------------
+// Both launchers run in plan mode (nothing touches the GPU): the answer is exactly "nfp_pool_forward AND
+// nfp_pool_backward would launch", whatever the LDS sizing rules of the kernels are this week.  (Round 2 re-derived
+// the backward's table size here and forgot the forward's slab: 576 descriptors with R = 2 and P >= 256 were promised
+// and then refused — ADVICE round 2.)
+static int pool_plan(const KP& g, bool backward) {
+  const bool was_dry = t_dry;
+  char keep_variant[sizeof(g_variant)], keep_plan[sizeof(t_plan)], keep_err[sizeof(g_err)];
+  memcpy(keep_variant, g_variant, sizeof(keep_variant));
+  memcpy(keep_plan, t_plan, sizeof(keep_plan));
+  memcpy(keep_err, g_err, sizeof(keep_err));
+  t_dry = true;
+  void* fake = (void*)(uintptr_t)0x1000;
+  int rc;
+  if (!backward) {
+    if (g.measure == NFP_COSINE)
+      rc = g.R == 1 ? pool_forward_rm<1, NFP_COSINE>(g, fake, fake, (float*)fake, nullptr, (float*)fake, (float*)fake)
+                    : pool_forward_rm<2, NFP_COSINE>(g, fake, fake, (float*)fake, nullptr, (float*)fake, (float*)fake);
+    else
+      rc = g.R == 1 ? pool_forward_rm<1, NFP_NORM>(g, fake, fake, (float*)fake, nullptr, (float*)fake, (float*)fake)
+                    : pool_forward_rm<2, NFP_NORM>(g, fake, fake, (float*)fake, nullptr, (float*)fake, (float*)fake);
+  } else {
+    if (g.measure == NFP_COSINE)
+      rc = g.R == 1 ? pool_backward_rm<1, NFP_COSINE>(g, fake, fake, (const float*)fake, fake, nullptr, (const float*)fake, (const float*)fake)
+                    : pool_backward_rm<2, NFP_COSINE>(g, fake, fake, (const float*)fake, fake, nullptr, (const float*)fake, (const float*)fake);
+    else
+      rc = g.R == 1 ? pool_backward_rm<1, NFP_NORM>(g, fake, fake, (const float*)fake, fake, nullptr, (const float*)fake, (const float*)fake)
+                    : pool_backward_rm<2, NFP_NORM>(g, fake, fake, (const float*)fake, fake, nullptr, (const float*)fake, (const float*)fake);
+  }
+  t_dry = was_dry;
+  memcpy(g_variant, keep_variant, sizeof(keep_variant));
+  memcpy(t_plan, keep_plan, sizeof(keep_plan));
+  memcpy(g_err, keep_err, sizeof(keep_err));
+  return rc;
+}
+
 int nfp_pool_supported(const nfp_desc* d) {
   KP g;
   if (make_kp(d, &g)) return 0;
-  // hot-path geometry (either layout, float32 or bf16) with its workspace tables; the backward's tables must fit LDS.
-  // Pointer alignment is the caller's: channels-last maps need 16-byte aligned images (as nfp_forward's hot path).
+  // hot-path geometry (either layout, float32 or bf16) with its workspace tables.  Pointer alignment is the caller's:
+  // channels-last maps need 16-byte aligned images (as nfp_forward's hot path).
   if (g.ws == nullptr || g.rs == 12 || !fast_ok(g, nullptr, nullptr)) return 0;
-  const int K2 = g.k * g.k;
-  const size_t bwd_tables = bwd_fixed_bytes(g, K2) + bwd_pair_bytes(g, g.measure, g.N);
-  return bwd_tables + 64 <= (size_t)kLdsMax ? 1 : 0;  // the x slab shares the pair values' region (dead by then)
+  if (g.B == 0) return 1;
+  return pool_plan(g, false) == NFP_OK && pool_plan(g, true) == NFP_OK ? 1 : 0;
 }
 
 

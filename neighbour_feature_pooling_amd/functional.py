@@ -141,30 +141,47 @@ def output_shape(d):
     return d.B, n.value, ho.value, wo.value
 
 
-_WORKSPACES = {}            # (device, geometry) -> uint8 tensor: the descriptor's constant tables, built once
+_WORKSPACES = {}            # (device, geometry) -> [uint8 tensor, fill event or None]: the descriptor's constant tables
 
 
 def _workspace(d, device):
     """Device pointer of the constant tables of `d` (include/nfp.h: nfp_workspace_bytes / nfp_workspace_init), or
     None.  They depend on the geometry only, so every call with the same map size and kernel shares one buffer per
-    device; the fill kernel is enqueued once, on the current stream (allocations made under a side stream or a graph
-    capture stay valid for later streams: the buffer is never freed while it is cached)."""
+    device.  The fill kernel is enqueued once, on the stream that first needs the tables, followed by an event; a later
+    call on ANOTHER stream makes that stream wait for the event (no host synchronisation), and once the event has
+    completed it is dropped.  Under a graph capture no table is built (the fill would only be recorded, not run, and a
+    later eager call would read an unfilled buffer): that one call is planned without tables and nothing is cached —
+    warm a geometry up before capturing it, as every graph user does anyway."""
     key = (device.index, d.H, d.W, d.R, d.pad, d.stride, d.dilation, d.pad_mode, d.inner_R)
-    ws = _WORKSPACES.get(key)
-    if ws is None:
+    rec = _WORKSPACES.get(key)
+    if rec is None:
         L = _abi.load()
         nbytes = int(L.nfp_workspace_bytes(ctypes.byref(d)))
-        if nbytes <= 0:
-            _WORKSPACES[key] = ws = False
+        if nbytes < 0:
+            return None     # the descriptor itself is refused (bad p / eps ...): say nothing about the GEOMETRY
+        if nbytes == 0:
+            _WORKSPACES[key] = rec = False
         else:
+            if torch.cuda.is_current_stream_capturing():
+                import warnings
+                warnings.warn("NFP: a geometry first seen inside a graph capture runs without its workspace tables "
+                              "(general kernels); call the op once before capturing", RuntimeWarning, stacklevel=4)
+                return None
             with _on_device(device):
                 ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
                 _abi.check(L.nfp_workspace_init(ctypes.byref(d), ws.data_ptr(), _raw_stream(device)))
-                # the tables are read by later launches on ANY stream: make the fill visible to all of them once
-                if not torch.cuda.is_current_stream_capturing():
-                    torch.cuda.current_stream(device).synchronize()
-            _WORKSPACES[key] = ws
-    return ws.data_ptr() if ws is not False else None
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(device))
+            _WORKSPACES[key] = rec = [ws, ev, _raw_stream(device)]
+    if rec is False:
+        return None
+    if rec[1] is not None:
+        # the fill is ordered before later work of its own stream; any other stream waits for it on the device
+        if rec[1].query():
+            rec[1] = None
+        elif _raw_stream(device) != rec[2]:
+            torch.cuda.current_stream(device).wait_event(rec[1])
+    return rec[0].data_ptr()
 
 
 _DESC_TENSORS = {}          # id(descriptor) -> (descriptor, uint8 tensor over its bytes)
@@ -197,11 +214,13 @@ def _plan(x, layout, cfg):
         L = _abi.load()
         d = make_desc(x, cfg, layout)
         d.ws = _workspace(d, x.device)
+        cacheable = d.ws is not None or not torch.cuda.is_current_stream_capturing()
         buf = ctypes.create_string_buffer(1024)
         rc = L.nfp_plan(ctypes.byref(d), 1, buf, len(buf))
         no_bwd = None if rc == 0 else L.nfp_last_error().decode()
         plan = (d, output_shape(d), int(L.nfp_saved_floats(ctypes.byref(d))), no_bwd)
-        _plans_put(key, plan)
+        if cacheable:
+            _plans_put(key, plan)
         _DESC_TENSORS[id(d)] = (d, torch.frombuffer(d, dtype=torch.uint8))   # (same memory; for the C++ nodes)
         if len(_DESC_TENSORS) > 4 * _PLANS_MAX:
             live = {id(p[0]) for p in _PLANS.values() if isinstance(p, tuple)}
@@ -339,14 +358,17 @@ def nfp_pool(x, cfg):
     """(GAP(x) [B,C], GAP(NFP(x)) [B,N]) — NFP_Pooling.py:27-31.  Fused on the GPU where supported,
     otherwise the same two reductions composed from `nfp` and torch ops."""
     if x.dim() == 4 and nfp_pool_fused_ok(x, cfg):
-        cpp = _cpp_nodes()
-        if cpp:
-            xd, layout = _dense(x)
-            d, oshape, ns, _ = _plan(xd, layout, cfg)
-            gap, nfpm = _cpp_call(cpp.nfp_pool_apply, xd, _DESC_TENSORS[id(d)][1], list(oshape), max(ns, 0),
-                                  layout == "nhwc")
-            return gap, nfpm
-        return _NfpPoolHip.apply(x, cfg)
+        try:
+            cpp = _cpp_nodes()
+            if cpp:
+                xd, layout = _dense(x)
+                d, oshape, ns, _ = _plan(xd, layout, cfg)
+                gap, nfpm = _cpp_call(cpp.nfp_pool_apply, xd, _DESC_TENSORS[id(d)][1], list(oshape), max(ns, 0),
+                                      layout == "nhwc")
+                return gap, nfpm
+            return _NfpPoolHip.apply(x, cfg)
+        except _abi.NfpUnsupported:
+            pass    # (nfp_pool_supported is a dry run of both launchers; should it ever disagree, the composition serves)
     return x.mean((2, 3)), nfp(x, cfg).mean((2, 3))
 
 
