@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define NFP_ABI_VERSION 4
+#define NFP_ABI_VERSION 5
 
 /* error codes */
 #define NFP_OK 0
@@ -143,11 +143,16 @@ int nfp_backward(const nfp_desc* d, const void* x, const void* grad_out, const v
  *   gap  [B,C] f32 = AdaptiveAvgPool2d(1)(x)                          NFP_Pooling.py:27
  *   nfpm [B,N] f32 = adaptive_avg_pool2d(NFPPooling(x), 1)            NFP_Pooling.py:29-31
  * out_map [B,N,Ho,Wo] (dtype of x) is also written: the backward needs it, callers may ignore it.
- * Served only where nfp_pool_supported(d) != 0 — cosine / L2 on "same" maps (stride 1, padding = R) with the descriptor's
- * workspace set, NCHW or channels-last, float32 or bf16; the answer is a dry run of both launchers, so a 1 means both
- * nfp_pool_forward and nfp_pool_backward will launch.  Otherwise compose nfp_forward with ordinary pooling.
+ * Served only where nfp_pool_supported(d) != 0 — cosine / L2 on "same" maps (stride 1, padding = R) of any size, NCHW or
+ * channels-last, float32 or bf16 (maps of at most 512 pixels: with the descriptor's workspace set); the answer is a dry
+ * run of both launchers, so a 1 means both nfp_pool_forward and nfp_pool_backward will launch.  Otherwise compose
+ * nfp_forward with ordinary pooling.
  */
 int nfp_pool_supported(const nfp_desc* d);
+/* Floats of `saved` the fused tail needs: the per-pixel state of nfp_saved_floats plus, for maps served by the row-band
+ * kernels (above 512 pixels), every band's share of the two pooled sums (joined in a fixed order by a second, tiny
+ * launch).  nfp_pool_forward requires a non-NULL `saved` of at least this size (min 1 float). */
+int64_t nfp_pool_saved_floats(const nfp_desc* d);
 int nfp_pool_forward(const nfp_desc* d, const void* x, float* gap, float* nfpm, void* out_map, float* saved,
                      void* hip_stream);
 /* grad_x = d( sum(gap*grad_gap) + sum(nfpm*grad_nfpm) ) / dx;  out_map / saved from nfp_pool_forward. */

@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libnfp_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 MEASURES = ["norm", "cosine", "dot", "rmse", "geman", "attention", "emd", "canberra", "hellinger",
             "chisquared1", "chisquared2", "gfc", "pearson", "jeffrey", "squaredchord", "smith", "scs"]
@@ -18,7 +18,7 @@ PAD_MODES = ["zeros", "reflect", "replicate", "circular"]
 F32, BF16 = 0, 1
 
 EXPORTS = ["nfp_abi_version", "nfp_last_error", "nfp_output_shape", "nfp_saved_floats", "nfp_forward",
-           "nfp_backward", "nfp_pool_supported", "nfp_pool_forward", "nfp_pool_backward", "nfp_launch_count",
+           "nfp_backward", "nfp_pool_supported", "nfp_pool_saved_floats", "nfp_pool_forward", "nfp_pool_backward", "nfp_launch_count",
            "nfp_last_variant", "nfp_plan", "nfp_reload_env", "nfp_workspace_bytes", "nfp_workspace_init", "nfp_time_next_launch"]
 
 
@@ -72,6 +72,8 @@ def load():
     L.nfp_forward.argtypes = [dp, vp, vp, vp, vp]
     L.nfp_backward.argtypes = [dp, vp, vp, vp, vp, vp, vp]
     L.nfp_pool_supported.argtypes = [dp]
+    L.nfp_pool_saved_floats.argtypes = [dp]
+    L.nfp_pool_saved_floats.restype = ctypes.c_int64
     L.nfp_pool_forward.argtypes = [dp, vp, vp, vp, vp, vp, vp]
     L.nfp_pool_backward.argtypes = [dp, vp, vp, vp, vp, vp, vp, vp]
     if L.nfp_abi_version() != ABI_VERSION:

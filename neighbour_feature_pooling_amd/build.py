@@ -10,11 +10,11 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB = os.path.join(_HERE, "libnfp_hip.so")
-SOURCES = ["nfp_hip.hip"]
+SOURCES = ["nfp_hip.hip", "nfp_tile.hip"]   # two translation units, compiled in parallel
 # -fno-slp-vectorize: left to itself hipcc packs adjacent scalar f32 FMAs of the channel loops into v_pk_fma_f32,
 # which costs more issue time than it saves at two wavefronts per SIMD (headline forward 5.31 -> 5.10 us,
 # [256,512,7,7] forward 7.8 -> 7.5 us; scripts/ab_flags.py)
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-slp-vectorize",
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize",
                "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 
 
@@ -29,14 +29,32 @@ def hipcc_path():
     return shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
 
+def compile_hip(out_lib, extra_flags=(), verbose=False):
+    """hipcc: every source of SOURCES to an object (in parallel), then one shared library."""
+    import concurrent.futures as cf
+    import tempfile
+    with tempfile.TemporaryDirectory(prefix="nfp_build_") as tmp:
+        def one(src):
+            obj = os.path.join(tmp, src + ".o")
+            cmd = [hipcc_path()] + HIPCC_FLAGS + list(extra_flags) + ["-c", "-o", obj, os.path.join(CSRC, src)]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+            return obj
+        with cf.ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
+            objs = list(ex.map(one, SOURCES))
+        cmd = [hipcc_path(), "--offload-arch=gfx950", "-fPIC", "-shared", "-fno-gpu-rdc", "-o", out_lib] + objs
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return out_lib
+
+
 def build_hip(force=False, verbose=False):
     """Compile csrc/*.hip -> libnfp_hip.so.  Returns the library path."""
     if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= _newest_source_mtime():
         return LIB
-    cmd = [hipcc_path()] + HIPCC_FLAGS + ["-o", LIB + ".tmp"] + [os.path.join(CSRC, s) for s in SOURCES]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    compile_hip(LIB + ".tmp", verbose=verbose)
     os.replace(LIB + ".tmp", LIB)
     return LIB
 

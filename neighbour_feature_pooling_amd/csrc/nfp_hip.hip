@@ -3,20 +3,7 @@
 // Stands in for models/pooling/nfp.py::NFPPooling.forward (nfp.py:132-134) and its
 // autograd backward.  gfx950 only; no CPU path lives here — the library fails
 // loudly (NFP_E_HIP / NFP_E_UNSUPPORTED) rather than fall back.
-#include <hip/hip_runtime.h>
-#include <hip/hip_ext.h>
-
-#include <algorithm>
-#include <atomic>
-#include <cstdarg>
-#include <cstdio>
-#include <cstring>
-#include <mutex>
-#include <unordered_map>
-#include <vector>
-
-#include <cstdlib>
-
+#include "nfp_launch.h"
 #include "nfp_fast.h"
 #include "nfp_band.h"
 #include "nfp_gather.h"
@@ -24,65 +11,13 @@
 #include "nfp_direct.h"
 
 using namespace nfp;
+using namespace nfp_host;
 
 namespace {
 
-thread_local char g_err[512] = "";
-// The dispatcher names the variant it picked in a buffer of the CALLING thread (forward and autograd's backward
-// thread dispatch concurrently); a finished nfp_forward / nfp_backward publishes it under a lock as the process's
-// "last variant", which nfp_last_variant() copies back into the reader's own thread.
-thread_local char g_variant[64] = "";
-thread_local char t_variant_out[64] = "";
-std::mutex g_variant_mu;
-char g_variant_last[64] = "";
-std::atomic<uint64_t> g_launches{0};
-std::atomic<void*> g_time_start{nullptr}, g_time_stop{nullptr};  // nfp_time_next_launch (process-wide: backward launches from autograd's thread)
-
-void publish_variant() {
-  std::lock_guard<std::mutex> lock(g_variant_mu);
-  memcpy(g_variant_last, g_variant, sizeof(g_variant_last));
-}
-
-// Test / A-B switches, read from the environment ONCE when the library is loaded (and again only when a test
-// calls nfp_reload_env): the launch path itself never calls getenv.
-struct Switches {
-  std::atomic<int> fwd_scalar{0}, bwd_atomic{0}, bwd_bands{0}, force_generic{0}, mfma{1};
-};
-Switches g_sw;
-#ifndef NFP_MFMA_DEFAULT
-#define NFP_MFMA_DEFAULT 1
-#endif
-void read_env() {
-  auto flag = [](const char* name, int dflt) {
-    const char* e = getenv(name);
-    return e ? (e[0] == '1' ? 1 : 0) : dflt;
-  };
-  g_sw.fwd_scalar = flag("NFP_FWD_SCALAR", 0);
-  g_sw.bwd_atomic = flag("NFP_BWD_ATOMIC", 0);
-  g_sw.force_generic = flag("NFP_FORCE_GENERIC", 0);
-  g_sw.mfma = flag("NFP_MFMA", NFP_MFMA_DEFAULT);
-  const char* e = getenv("NFP_BWD_BANDS");
-  g_sw.bwd_bands = e ? atoi(e) : 0;
-}
 struct EnvInit {
   EnvInit() { read_env(); }
 } g_env_init;
-
-int fail(int code, const char* fmt, ...) {
-  va_list ap;
-  va_start(ap, fmt);
-  vsnprintf(g_err, sizeof(g_err), fmt, ap);
-  va_end(ap);
-  return code;
-}
-
-int hip_ok(hipError_t e, const char* what) {
-  if (e == hipSuccess) return NFP_OK;
-  return fail(NFP_E_HIP, "%s: %s", what, hipGetErrorString(e));
-}
-
-constexpr int kLdsMax = 160 * 1024;
-constexpr int kNotApplicable = 1;  // internal: a hot-path launcher declined, use the generic kernels
 
 // Validate the descriptor the way nn.Conv2d / F.pad would and fill the kernel parameter block.
 int make_kp(const nfp_desc* d, KP* g) {
@@ -138,67 +73,6 @@ int make_kp(const nfp_desc* d, KP* g) {
     return fail(NFP_E_UNSUPPORTED, "feature map [%d,%d,%d,%d] with k = %d exceeds the index range of the kernels", d->B,
                 d->C, d->H, d->W, k);
   return NFP_OK;
-}
-
-// floats per input pixel that forward hands to backward
-int stats_of(int measure) {
-  switch (measure) {
-    case NFP_COSINE: case NFP_GFC: case NFP_SMITH: return 1;
-    case NFP_PEARSON: return 2;
-    default: return 0;
-  }
-}
-
-// Kernels that want more than 64 KiB of dynamic LDS must be told so once (per kernel and size class);
-// remembered here so that steady-state launches make no extra runtime call.
-template <typename K>
-int set_lds(K kernel, size_t bytes) {
-  if (bytes <= 64 * 1024) return NFP_OK;
-  // hipFuncSetAttribute applies to the kernel ON THE CURRENT DEVICE: remembered per (device, kernel)
-  static std::mutex mu;
-  static std::unordered_map<uintptr_t, size_t> granted;
-  int dev = 0;
-  if (int rc = hip_ok(hipGetDevice(&dev), "hipGetDevice")) return rc;
-  std::lock_guard<std::mutex> lock(mu);
-  size_t& have = granted[(uintptr_t)(const void*)kernel * 64 + (uintptr_t)(dev & 63)];
-  if (have >= bytes) return NFP_OK;
-  if (int rc = hip_ok(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMax),
-                      "hipFuncSetAttribute(max dynamic LDS)"))
-    return rc;
-  have = kLdsMax;
-  return NFP_OK;
-}
-
-// One way to launch: host-side limits first (a launch the hardware would refuse or fault on is never
-// attempted), then the LDS opt-in, the launch and its error.  In plan mode (nfp_plan) nothing touches the
-// GPU: the launch is only described, so the dispatcher's decisions are testable without a device.
-thread_local bool t_dry = false;
-thread_local char t_plan[512] = "";
-
-template <typename K, typename... A>
-int launch(const char* name, K kernel, dim3 grid, dim3 block, size_t lds, hipStream_t st, A... args) {
-  if (lds > (size_t)kLdsMax || block.x < 1 || block.x > 1024 || grid.x < 1 || grid.y < 1 || grid.z < 1 ||
-      grid.y > 65535 || grid.z > 65535)
-    return fail(NFP_E_UNSUPPORTED, "%s: launch shape grid (%u,%u,%u) block %u lds %zu outside the device limits", name,
-                grid.x, grid.y, grid.z, block.x, lds);
-  if (t_dry) {
-    const size_t n = strlen(t_plan);
-    snprintf(t_plan + n, sizeof(t_plan) - n, "%s%s grid=(%u,%u,%u) block=%u lds=%zu", n ? "; " : "", name, grid.x, grid.y,
-             grid.z, block.x, lds);
-    return NFP_OK;
-  }
-  if (int rc = set_lds(kernel, lds)) return rc;
-  // telemetry (nfp_time_next_launch): bracket this one kernel with the caller's events — recorded by the command
-  // processor at the kernel's own start and end, like a profiler's kernel trace
-  hipEvent_t ev0 = name[0] != '#' ? (hipEvent_t)g_time_start.exchange(nullptr) : nullptr;
-  if (ev0 != nullptr) {
-    hipEvent_t ev1 = (hipEvent_t)g_time_stop.exchange(nullptr);
-    hipExtLaunchKernelGGL(kernel, grid, block, lds, st, ev0, ev1, 0, args...);
-  } else {
-    hipLaunchKernelGGL(kernel, grid, block, lds, st, args...);
-  }
-  if (name[0] != '#') g_launches++;  // ('#': one-time setup kernels, not part of a forward / backward)
-  return hip_ok(hipGetLastError(), name);
 }
 
 // ---- generic launches -----------------------------------------------------------------------
@@ -440,7 +314,6 @@ int launch_bwd_generic(KP g, const void* x, const void* go, const void* out, con
 #endif
 constexpr int kSlabBudgetBwd = NFP_BWD_SLAB_KB * 1024;
 
-bool force_generic() { return g_sw.force_generic.load(std::memory_order_relaxed) != 0; }
 
 // Geometry of the hot path: "same" maps (stride 1, dilation 1, pad = R) small enough for one workgroup per image.
 // These are the descriptors that have workspace tables (nfp_tables.h).
@@ -465,12 +338,6 @@ bool fast_ok(const KP& g, const void* x, const void* gx) {
   return true;
 }
 
-int round4(int v) { return (v + 3) & ~3; }
-// fewest groups (<= gmax) that still finish ncq channel quads in ceil(ncq/gmax) rounds
-int even_groups(int ncq, int gmax) {
-  int rounds = (ncq + gmax - 1) / gmax;
-  return (ncq + rounds - 1) / rounds;
-}
 
 // channels per LDS chunk: bounded by the slab budget and by what one staging round-set can carry
 int chunk_channels(const KP& g, int total, int T, int G, bool nhwc, int budget) {
@@ -772,6 +639,8 @@ int forward_impl(const nfp_desc* d, const void* x, void* out, float* saved, void
                     : launch_fwd_band<2, NFP_NORM>(g, x, out, saved, st);
     if (rc != kNotApplicable) return rc;
   }
+  // maps above the table kernels' 512 pixels, or a descriptor without its tables: the row-band kernels (nfp_tile.hip)
+  if (int rc = tile_forward(g, x, out, saved, st, false, nullptr, nullptr); rc != kNotApplicable) return rc;
   switch (g.measure) {
     case NFP_COSINE: return launch_fwd_generic<NFP_COSINE>(g, x, out, saved, st);
     case NFP_NORM:
@@ -837,6 +706,7 @@ int backward_impl(const nfp_desc* d, const void* x, const void* grad_out, const 
                     : launch_bwd_fast<2, NFP_NORM>(g, x, grad_out, out, saved, grad_x, st);
     if (rc != kNotApplicable) return rc;
   }
+  if (int rc = tile_backward(g, x, grad_out, out, saved, grad_x, st, false, nullptr, nullptr); rc != kNotApplicable) return rc;
   switch (g.measure) {
     case NFP_COSINE: return launch_bwd_generic<NFP_COSINE>(g, x, grad_out, out, saved, grad_x, st);
     case NFP_NORM:
@@ -872,31 +742,55 @@ int backward_impl(const nfp_desc* d, const void* x, const void* grad_out, const 
   }
 }
 
+// Floats of scratch behind the per-pixel state in `saved` that the row-band pooled forward needs: every band's share of
+// the two pooled sums (nfp_tile.h::fwd_tile<POOL> -> pool_fold).  Set by pool_forward_rm (also in plan mode).
+thread_local long long t_pool_scratch = 0;
+
 template <int R, int M>
 int pool_forward_rm(const KP& g, const void* x, void* out_map, float* saved, hipStream_t st, float* gap, float* nfpm) {
   const bool bf = g.dtype == NFP_BF16, nhwc = !g.contig;
-  if (bf) {  // the matrix-core forward where it applies, as in nfp_forward
-    const int rc = launch_fwd_gram<R, M>(g, x, out_map, saved, st, gap, nfpm);
+  t_pool_scratch = 0;
+  if (g.ws != nullptr && fast_ok(g, x, x)) {
+    int rc;
+    if (bf) {  // the matrix-core forward where it applies, as in nfp_forward
+      rc = launch_fwd_gram<R, M>(g, x, out_map, saved, st, gap, nfpm);
+      if (rc != kNotApplicable) return rc;
+    }
+    if (bf) rc = nhwc ? launch_fwd_band_t<R, M, true, true, true>(g, x, out_map, saved, st, gap, nfpm)
+                      : launch_fwd_band_t<R, M, true, false, true>(g, x, out_map, saved, st, gap, nfpm);
+    else rc = nhwc ? launch_fwd_band_t<R, M, false, true, true>(g, x, out_map, saved, st, gap, nfpm)
+                   : launch_fwd_band_t<R, M, false, false, true>(g, x, out_map, saved, st, gap, nfpm);
     if (rc != kNotApplicable) return rc;
   }
-  if (bf) return nhwc ? launch_fwd_band_t<R, M, true, true, true>(g, x, out_map, saved, st, gap, nfpm)
-                      : launch_fwd_band_t<R, M, true, false, true>(g, x, out_map, saved, st, gap, nfpm);
-  return nhwc ? launch_fwd_band_t<R, M, false, true, true>(g, x, out_map, saved, st, gap, nfpm)
-              : launch_fwd_band_t<R, M, false, false, true>(g, x, out_map, saved, st, gap, nfpm);
+  if (!tile_ok(g, x, x)) return kNotApplicable;
+  // row bands (any map size): per-band partial sums into the scratch behind the norms, joined by pool_fold
+  if (saved == nullptr) return fail(NFP_E_INVALID, "fused pooling tail on this map needs the scratch of nfp_pool_saved_floats");
+  float* part = saved + (long long)stats_of(g.measure) * g.B * g.P;
+  int nb = 0;
+  if (int rc = tile_forward(g, x, out_map, saved, st, true, part, &nb); rc != NFP_OK) return rc;
+  t_pool_scratch = (long long)g.B * nb * (g.C + g.N);
+  strncat(g_variant, "+pool_fold", sizeof(g_variant) - strlen(g_variant) - 1);
+  return tile_pool_fold(g, part, gap, nfpm, nb, st);
 }
 template <int R, int M>
 int pool_backward_rm(const KP& g, const void* x, const void* out_map, const float* saved, void* gx, hipStream_t st,
                      const float* ggap, const float* gnfpm) {
   const bool bf = g.dtype == NFP_BF16, nhwc = !g.contig;
-  if (bf) {  // phase B on the matrix cores where it applies, as in nfp_backward
-    const int rc = nhwc ? launch_bwd_gemm_t<R, M, true, true>(g, x, nullptr, out_map, saved, gx, st, ggap, gnfpm)
-                        : launch_bwd_gemm_t<R, M, false, true>(g, x, nullptr, out_map, saved, gx, st, ggap, gnfpm);
-    if (rc != kNotApplicable) return rc;
-    return nhwc ? launch_bwd_fast_t<R, M, true, true, true>(g, x, nullptr, out_map, saved, gx, st, ggap, gnfpm)
+  if (g.ws != nullptr && fast_ok(g, x, gx)) {
+    int rc;
+    if (bf) {  // phase B on the matrix cores where it applies, as in nfp_backward
+      rc = nhwc ? launch_bwd_gemm_t<R, M, true, true>(g, x, nullptr, out_map, saved, gx, st, ggap, gnfpm)
+                : launch_bwd_gemm_t<R, M, false, true>(g, x, nullptr, out_map, saved, gx, st, ggap, gnfpm);
+      if (rc != kNotApplicable) return rc;
+      rc = nhwc ? launch_bwd_fast_t<R, M, true, true, true>(g, x, nullptr, out_map, saved, gx, st, ggap, gnfpm)
                 : launch_bwd_fast_t<R, M, true, false, true>(g, x, nullptr, out_map, saved, gx, st, ggap, gnfpm);
+    } else {
+      rc = nhwc ? launch_bwd_fast_t<R, M, false, true, true>(g, x, nullptr, out_map, saved, gx, st, ggap, gnfpm)
+                : launch_bwd_fast_t<R, M, false, false, true>(g, x, nullptr, out_map, saved, gx, st, ggap, gnfpm);
+    }
+    if (rc != kNotApplicable) return rc;
   }
-  return nhwc ? launch_bwd_fast_t<R, M, false, true, true>(g, x, nullptr, out_map, saved, gx, st, ggap, gnfpm)
-              : launch_bwd_fast_t<R, M, false, false, true>(g, x, nullptr, out_map, saved, gx, st, ggap, gnfpm);
+  return tile_backward(g, x, nullptr, out_map, saved, gx, st, true, ggap, gnfpm);
 }
 
 }  // namespace
@@ -1032,24 +926,35 @@ static int pool_plan(const KP& g, bool backward) {
   return rc;
 }
 
+static bool pool_measure_ok(const KP& g) {
+  return g.rs != 12 && (g.measure == NFP_COSINE || (g.measure == NFP_NORM && g.p == 2.f));
+}
+
 int nfp_pool_supported(const nfp_desc* d) {
   KP g;
   if (make_kp(d, &g)) return 0;
-  // hot-path geometry (either layout, float32 or bf16) with its workspace tables.  Pointer alignment is the caller's:
-  // channels-last maps need 16-byte aligned images (as nfp_forward's hot path).
-  if (g.ws == nullptr || g.rs == 12 || !fast_ok(g, nullptr, nullptr)) return 0;
+  // cosine / L2 on "same" maps, either layout, float32 or bf16: the table kernels (<= 512 pixels, descriptor with its
+  // workspace) or the row-band kernels (any size).  Pointer alignment is the caller's: channels-last maps need 16-byte
+  // aligned images (as nfp_forward's hot path).
+  if (!pool_measure_ok(g)) return 0;
   if (g.B == 0) return 1;
   return pool_plan(g, false) == NFP_OK && pool_plan(g, true) == NFP_OK ? 1 : 0;
 }
 
+int64_t nfp_pool_saved_floats(const nfp_desc* d) {
+  KP g;
+  if (make_kp(d, &g)) return -1;
+  if (!pool_measure_ok(g) || g.B == 0) return 0;
+  if (pool_plan(g, false) != NFP_OK) return 0;
+  return (int64_t)stats_of(g.measure) * g.B * g.P + t_pool_scratch;
+}
 
 int nfp_pool_forward(const nfp_desc* d, const void* x, float* gap, float* nfpm, void* out_map, float* saved,
                      void* hip_stream) {
   KP g;
   if (int rc = make_kp(d, &g)) return rc;
   if (!x || !gap || !nfpm || !out_map) return fail(NFP_E_INVALID, "null tensor pointer");
-  if (!nfp_pool_supported(d) || !fast_ok(g, x, x))
-    return fail(NFP_E_UNSUPPORTED, "fused pooling tail: hot-path geometry, descriptor with a workspace only");
+  if (!pool_measure_ok(g)) return fail(NFP_E_UNSUPPORTED, "fused pooling tail: cosine / L2 (norm p=2), one radius");
   if (g.B == 0) return NFP_OK;
   hipStream_t st = (hipStream_t)hip_stream;
   int rc;
@@ -1067,8 +972,7 @@ int nfp_pool_backward(const nfp_desc* d, const void* x, const float* grad_gap, c
   KP g;
   if (int rc = make_kp(d, &g)) return rc;
   if (!x || !grad_gap || !grad_nfpm || !out_map || !grad_x) return fail(NFP_E_INVALID, "null tensor pointer");
-  if (!nfp_pool_supported(d) || !fast_ok(g, x, grad_x))
-    return fail(NFP_E_UNSUPPORTED, "fused pooling tail: hot-path geometry, descriptor with a workspace only");
+  if (!pool_measure_ok(g)) return fail(NFP_E_UNSUPPORTED, "fused pooling tail: cosine / L2 (norm p=2), one radius");
   if (stats_of(g.measure) > 0 && !saved) return fail(NFP_E_INVALID, "missing saved state");
   if (g.B == 0) return NFP_OK;
   hipStream_t st = (hipStream_t)hip_stream;

@@ -305,7 +305,8 @@ class _NfpPoolHip(torch.autograd.Function):
     def forward(ctx, x, cfg):
         L = _abi.load()
         x, layout = _dense(x)
-        d, (B, N, Ho, Wo), ns, _ = _plan(x, layout, cfg)
+        d, (B, N, Ho, Wo), _, _ = _plan(x, layout, cfg)
+        ns = _pool_saved_floats(x, layout, cfg, d)
         with _on_device(x.device):
             gap = torch.empty(B, x.shape[1], dtype=torch.float32, device=x.device)
             nfpm = torch.empty(B, N, dtype=torch.float32, device=x.device)
@@ -336,9 +337,19 @@ class _NfpPoolHip(torch.autograd.Function):
         return gx, None
 
 
+def _pool_saved_floats(x, layout, cfg, d):
+    """nfp_pool_saved_floats of the plan's descriptor (cached with the plans)."""
+    key = ("pool_ns", tuple(x.shape), x.stride(0), layout, x.dtype, cfg, x.device.index)
+    ns = _plans_get(key)
+    if ns is None:
+        ns = int(_abi.load().nfp_pool_saved_floats(ctypes.byref(d)))
+        _plans_put(key, ns)
+    return ns
+
+
 def nfp_pool_fused_ok(x, cfg):
-    """True when the fused GAP + pooled-NFP kernels can serve this call: hot-path geometry (stride 1, pad = R, cosine
-    or L2), float32 or bfloat16, images dense in NCHW or channels-last order."""
+    """True when the fused GAP + pooled-NFP kernels can serve this call: "same" maps (stride 1, pad = R) of any size,
+    cosine or L2, float32 or bfloat16, images dense in NCHW or channels-last order."""
     if not (x.is_cuda and x.dim() == 4 and x.dtype in _DTYPES):
         return False
     layout = _inner_layout(x)
@@ -362,7 +373,8 @@ def nfp_pool(x, cfg):
             cpp = _cpp_nodes()
             if cpp:
                 xd, layout = _dense(x)
-                d, oshape, ns, _ = _plan(xd, layout, cfg)
+                d, oshape, _, _ = _plan(xd, layout, cfg)
+                ns = _pool_saved_floats(xd, layout, cfg, d)
                 gap, nfpm = _cpp_call(cpp.nfp_pool_apply, xd, _DESC_TENSORS[id(d)][1], list(oshape), max(ns, 0),
                                       layout == "nhwc")
                 return gap, nfpm

@@ -31,11 +31,9 @@ def build_all(variants):
     def one(i_fl):
         i, fl = i_fl
         lib = os.path.join(AB, f"libnfp_ab_{i}.so")
-        subprocess.check_call([build.hipcc_path()] + build.HIPCC_FLAGS + ["-w"] + fl.split() + ["-o", lib,
-                              os.path.join(build.CSRC, "nfp_hip.hip")])
-        return lib
+        return build.compile_hip(lib, ["-w"] + fl.split())
 
-    with cf.ThreadPoolExecutor(max_workers=6) as ex:
+    with cf.ThreadPoolExecutor(max_workers=3) as ex:
         libs = list(ex.map(one, enumerate(variants)))
     json.dump([{"flags": fl, "lib": os.path.relpath(lib, ROOT)} for fl, lib in zip(variants, libs)],
               open(MANIFEST, "w"), indent=1)

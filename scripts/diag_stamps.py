@@ -14,8 +14,7 @@ from neighbour_feature_pooling_amd import _abi, build
 # built in-tree (git-ignored *.so) so that a copy compiled in the CPU container travels to the GPU box
 diag = os.path.join(ROOT, "neighbour_feature_pooling_amd", "libnfp_hip_diag.so")
 if not os.path.exists(diag) or os.path.getmtime(diag) < build._newest_source_mtime():
-    subprocess.check_call([build.hipcc_path()] + build.HIPCC_FLAGS + ["-DNFP_STAMPS", "-o", diag,
-                          os.path.join(build.CSRC, "nfp_hip.hip")])
+    build.compile_hip(diag, ["-DNFP_STAMPS"])
 if "--build-only" in sys.argv:
     sys.exit(0)
 _abi.LIB_PATH = diag

@@ -77,8 +77,10 @@ def test_plan_does_not_launch_or_disturb_last_variant(lib):
     (dict(shape=(4, 64, 7, 7), mode="circular"), "fwd_pairs", "bwd_gather"),
     (dict(shape=(4, 64, 7, 7), measure="jeffrey"), "fwd_pairs", "bwd_gather"),
     (dict(shape=(4, 64, 7, 7), measure="attention"), "fwd_pairs+attn_softmax", "bwd_gather"),
-    (dict(shape=(64, 64, 56, 56)), "fwd_pairs", "bwd_gather_banded"),                                   # tables > LDS
-    (dict(shape=(2, 8, 100, 140)), "fwd_pairs", "bwd_gather_banded"),
+    (dict(shape=(64, 64, 56, 56)), "fwd_tile<R1,cos,f32,nchw>x8", "bwd_tile<R1,cos,f32,nchw>x8"),     # > 512 px: row bands
+    (dict(shape=(256, 16, 112, 112)), "fwd_tile<R1,cos,f32,nchw>x19", "bwd_tile<R1,cos,f32,nchw>x28"),
+    (dict(shape=(2, 8, 100, 140)), "fwd_tile<R1,cos,f32,nchw>x100", "bwd_tile<R1,cos,f32,nchw>x100"),
+    (dict(shape=(2, 8, 100, 140), measure="emd"), "fwd_pairs", "bwd_gather_banded"),                   # tables > LDS
     (dict(shape=(2, 16, 64, 64), mode="circular"), "fwd_pairs", "bwd_direct"),                        # wraps: no bands
 ])
 def test_which_kernel_serves_which_call(lib, d_kw, fwd, bwd):

@@ -619,8 +619,11 @@ def test_gather_backward_geometry_sweep(B, C, H, W, R, pad, stride, dil, mode, m
     (1, 6, 90, 33, dict(R=1, measure="pearson", padding=2, dilation=2)),
     (3, 64, 56, 56, dict(R=1, measure="cosine", padding=1)),
 ])
-def test_large_maps_use_the_banded_backward(B, C, H, W, ctor, dev):
-    """Maps whose whole-image pair tables exceed LDS: row-windowed forward tiles, row-banded gather backward."""
+def test_large_maps_use_the_banded_backward(B, C, H, W, ctor, dev, monkeypatch):
+    """Maps whose whole-image pair tables exceed LDS: row-windowed forward tiles, row-banded gather backward.  (Cosine /
+    L2 "same" maps of this size are served by the row-band kernels of nfp_tile.h since round 3 — tests/test_gpu_tile.py;
+    the any-geometry kernels are forced here so that they stay covered on those shapes too.)"""
+    nfp_switch(monkeypatch, "NFP_FORCE_GENERIC", "1")
     from neighbour_feature_pooling_amd import NFPPooling, _abi
     from neighbour_feature_pooling_amd._host import nfp_host
     m = NFPPooling(C, **ctor)

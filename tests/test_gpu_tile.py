@@ -1,0 +1,101 @@
+"""The row-band kernels for maps above 512 pixels (csrc/nfp_tile.h: fwd_tile / bwd_tile) against the float64
+formulation of nfp.py:141-159 on the same inputs, every padding mode / radius / layout / storage type, with the
+dispatcher's choice asserted (these shapes must not fall to the any-geometry kernels)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def _cases():
+    cs = []
+    # the MultiStage / at-layer maps (texture_pooling.py:211-268, resnet18.py:410-468), small batches
+    for (C, H, W) in [(16, 112, 112), (24, 56, 56), (40, 28, 28), (128, 28, 28), (64, 56, 56)]:
+        cs.append((3, C, H, W, 1, "cosine", "reflect"))
+    cs += [(2, 16, 112, 112, 2, "norm", "reflect"), (9, 24, 56, 56, 1, "norm", "zeros"), (2, 40, 28, 28, 2, "cosine", "replicate"),
+           (1, 8, 30, 37, 1, "cosine", "reflect"),       # odd row length: unaligned rows, scalar pair-value loads
+           (2, 12, 23, 46, 2, "cosine", "zeros"), (17, 4, 40, 20, 1, "norm", "replicate"), (2, 8, 100, 140, 1, "cosine", "reflect"),
+           (1, 36, 33, 31, 2, "norm", "reflect"), (300, 8, 24, 24, 1, "cosine", "reflect"),
+           (2, 260, 26, 26, 1, "cosine", "reflect"),     # channel chunks
+           (1, 512, 23, 23, 1, "norm", "reflect"),       # one image: channel blocks in the backward
+           (2, 16, 6, 100, 2, "cosine", "reflect"), (2, 16, 200, 5, 2, "cosine", "replicate"), (1, 4, 3, 180, 1, "norm", "zeros")]
+    return cs
+
+
+def _run(B, C, H, W, R, meas, mode, dev, dtype=torch.float32, channels_last=False, similarity=True):
+    from neighbour_feature_pooling_amd import NFPPooling, _abi
+    from neighbour_feature_pooling_amd._host import nfp_host
+    from neighbour_feature_pooling_amd.synth import feature_map
+    ctor = dict(R=R, measure=meas, padding=R, padding_mode=mode, similarity=similarity)
+    if meas == "norm":
+        ctor["p"] = 2
+    m = NFPPooling(C, **ctor)
+    x = torch.from_numpy(feature_map((B, C, H, W), 5 * H + W + C)).to(dev).to(dtype)
+    if channels_last:
+        x = x.contiguous(memory_format=torch.channels_last)
+    x.requires_grad_(True)
+    L = _abi.load()
+    out = m(x)
+    fv = L.nfp_last_variant().decode()
+    go = torch.from_numpy(feature_map(tuple(out.shape), 3 * H + W)).to(dev).to(dtype)
+    gx, = torch.autograd.grad(out, x, go, retain_graph=True)
+    torch.cuda.synchronize()
+    bv = L.nfp_last_variant().decode()
+    gx2, = torch.autograd.grad(out, x, go)
+    out2 = m(x)
+    assert torch.equal(gx, gx2) and torch.equal(out, out2), "not bitwise reproducible"
+    x64 = x.detach().double().contiguous().requires_grad_(True)
+    ref = nfp_host(x64, m.config)
+    gref, = torch.autograd.grad(ref, x64, go.double())
+    return out.detach(), gx, ref.detach(), gref, fv, bv
+
+
+@pytest.mark.parametrize("B,C,H,W,R,meas,mode", _cases())
+@pytest.mark.parametrize("channels_last", [False, True])
+def test_tile_kernels_match_float64_formulation(B, C, H, W, R, meas, mode, channels_last):
+    dev = torch.device("cuda:0")
+    out, gx, ref, gref, fv, bv = _run(B, C, H, W, R, meas, mode, dev, channels_last=channels_last)
+    assert fv.startswith("fwd_tile<") and bv.startswith("bwd_tile<"), (fv, bv)
+    assert ("nhwc" in fv) == channels_last
+    assert rel_err(out.cpu().numpy(), ref.cpu().numpy()) <= TOL, fv
+    assert rel_err(gx.cpu().numpy(), gref.cpu().numpy()) <= TOL, bv
+    if meas == "norm":   # one sign, similar magnitudes: an element-wise bound is meaningful for distance maps
+        o, r = out.double().cpu().numpy(), ref.cpu().numpy()
+        assert np.all(np.abs(o - r) <= 1e-5 * np.abs(r) + 1e-6 * np.abs(r).max())
+
+
+@pytest.mark.parametrize("B,C,H,W,R,meas,mode", [(2, 16, 112, 112, 1, "cosine", "reflect"), (3, 24, 56, 56, 2, "norm", "reflect"),
+                                                   (2, 128, 28, 28, 1, "cosine", "zeros")])
+@pytest.mark.parametrize("channels_last", [False, True])
+def test_tile_kernels_bf16_storage(B, C, H, W, R, meas, mode, channels_last):
+    """bf16 load / store, f32 arithmetic: against the float64 formulation on the SAME bf16-rounded inputs."""
+    dev = torch.device("cuda:0")
+    out, gx, ref, gref, fv, bv = _run(B, C, H, W, R, meas, mode, dev, dtype=torch.bfloat16, channels_last=channels_last)
+    assert fv.startswith("fwd_tile<") and "bf16" in fv and bv.startswith("bwd_tile<"), (fv, bv)
+    assert rel_err(out.float().cpu().numpy(), ref.cpu().numpy()) <= 1e-2
+    assert rel_err(gx.float().cpu().numpy(), gref.cpu().numpy()) <= 2e-2
+
+
+def test_tile_kernels_dissimilarity_and_norm_quirk():
+    dev = torch.device("cuda:0")
+    out, gx, ref, gref, fv, bv = _run(2, 16, 40, 40, 1, "cosine", "reflect", dev, similarity=False)
+    assert fv.startswith("fwd_tile<")
+    assert rel_err(out.cpu().numpy(), ref.cpu().numpy()) <= TOL and rel_err(gx.cpu().numpy(), gref.cpu().numpy()) <= TOL
+    # measure='Norm' (capitalised): nfp.py:74 keeps the pure-neighbour weights while nfp.py:85 dispatches Norm
+    from neighbour_feature_pooling_amd import NFPPooling, _abi
+    from neighbour_feature_pooling_amd._host import nfp_host
+    m = NFPPooling(8, R=1, measure="Norm", p=2, padding=1)
+    x = torch.randn(2, 8, 30, 30, device=dev, requires_grad=True)
+    o = m(x)
+    assert _abi.load().nfp_last_variant().decode().startswith("fwd_tile<")
+    go = torch.randn_like(o)
+    g1, = torch.autograd.grad(o, x, go)
+    x64 = x.detach().double().requires_grad_(True)
+    r = nfp_host(x64, m.config)
+    g2, = torch.autograd.grad(r, x64, go.double())
+    assert rel_err(o.detach().cpu().numpy(), r.detach().cpu().numpy()) <= TOL
+    assert rel_err(g1.cpu().numpy(), g2.cpu().numpy()) <= TOL
