@@ -226,7 +226,7 @@ __global__ void __launch_bounds__(1024) fwd_band(const KP g, const void* __restr
   if (glf < Gn) {
     void* ob = (char*)out + (long long)b * N * P * ES;
     const float n2p = n2[lpf];
-    const float ip = inv_norm(n2p, g.inv_eps);
+    const float ip = g.unit ? 1.f : inv_norm(n2p, g.inv_eps);
     for (int n = glf; n < N; n += Gn) {
       const uint32_t e = n == glf ? fte : ftt[n * P + pf];
       const int kind = (int)(e >> 22), pix = (int)((e >> 9) & 511u), fi = (int)((e >> 18) & 15u);
@@ -236,22 +236,21 @@ __global__ void __launch_bounds__(1024) fwd_band(const KP g, const void* __restr
         const float n2q = n2[q - p0];
         float v;
         if (M == NFP_COSINE) {
-          const float s = kind == 2 ? 0.f : (kind == 1 ? n2p : pairv) * ip * inv_norm(n2q, g.inv_eps);
-          v = g.similarity ? s : 1.f - s;
+          const float s = kind == 2 ? 0.f : (kind == 1 ? n2p : pairv) * ip * (g.unit ? 1.f : inv_norm(n2q, g.inv_eps));
+          v = fin_prod(g, s);
         } else {
           float d2;
           if (g.diff)
             d2 = kind == 2 ? n2p : (kind == 1 ? 0.f : pairv);
           else
             d2 = kind == 2 ? 0.f : n2q;  // 'Norm' quirk (nfp.py:74 vs 85): |neighbour|
-          const float dd = __builtin_amdgcn_sqrtf(d2);
-          v = g.similarity ? -dd : dd;
+          v = fin_dist(g, d2);
         }
         stx(ob, n * P + pf, v, BF ? NFP_BF16 : NFP_F32);
         if constexpr (POOL) Tt[NV + n * Ps + lpf] = v;  // vm[n][p], behind the half-stencil table
       }
     }
-    if (M == NFP_COSINE && saved != nullptr && glf == 0 && pf < po) saved[(long long)b * P + pf] = __builtin_amdgcn_sqrtf(n2p);
+    if (M == NFP_COSINE && !g.unit && saved != nullptr && glf == 0 && pf < po) saved[(long long)b * P + pf] = __builtin_amdgcn_sqrtf(n2p);
   }
   if constexpr (POOL) {
     __syncthreads();

@@ -36,7 +36,22 @@ struct KP {
   int early;  // bwd_fast: the x slab lies beside the pair values (not over them): committed during phase A
   // host-computed reciprocals (hot path: exact small-integer division by float multiply)
   float invP, invW, invNQ, invPT, inv_eps;
+  // The hot-path kernels are instantiated for two per-channel forms — products (Cosine) and squared differences (L2) —
+  // and serve two more measures each through these run-time constants (make_kp), with no further instantiations:
+  //   out = osa * s + osb      products:   Cosine s, 1 - s (nfp.py:156-158); DotProduct (nfp.py:161-170): unit = 1 — the
+  //                                         norm factors are 1 and nothing pulls on |x| (no diagonal term)
+  //   out = osa * sqrt(d2 * d2s)  distances: Norm p=2 (nfp.py:141-148); RMSE (nfp.py:172-179): d2s = 1/C, and no
+  //                                         subgradient at distance 0 (zero0 = 0: torch's sqrt gives inf * 0 = NaN there)
+  float osa, osb, d2s;
+  int unit, zero0;
 };
+__device__ __forceinline__ float fin_prod(const KP& g, float s) { return fmaf(g.osa, s, g.osb); }
+__device__ __forceinline__ float fin_dist(const KP& g, float d2) { return g.osa * __builtin_amdgcn_sqrtf(d2 * g.d2s); }
+// per-pair backward scalar of a distance map: d out / d (a - b)[c] = coefficient * (a - b)[c]
+__device__ __forceinline__ float dist_coef(const KP& g, float gc, float oc) {
+  const float d = fabsf(oc);
+  return (d == 0.f && g.zero0) ? 0.f : g.osa * g.d2s * gc * __builtin_amdgcn_rcpf(d);
+}
 
 __device__ __forceinline__ float bf16_to_f32(uint16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 // round-to-nearest-even, NaN kept a NaN: gfx950 converts in hardware (v_cvt_pk_bf16_f32; the integer formula with its

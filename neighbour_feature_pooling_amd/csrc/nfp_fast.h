@@ -567,7 +567,8 @@ __global__ void __launch_bounds__(GEMM ? 1024 : kBwdThreads) bwd_fast(const KP g
     rows_load_to(prw0[k], prw1[k], ptq[k], entry_of(min(t + k * T, NE - 1), r_, j_));
   }
   pair_load_to(gq0, oq0, min(t * VP, NO - VP));
-  const float nrm = (M == NFP_COSINE) ? saved[(long long)b * P + min(t, P - 1)] : 0.f;
+  // (DotProduct has no saved norms: the load reads the output map instead — in bounds, unused — rather than sit under a branch)
+  const float nrm = (M == NFP_COSINE) ? (g.unit ? (const float*)out : saved)[(long long)b * P + min(t, P - 1)] : 0.f;
   uint4 bo[L_BRQ<R>::v];  // this pixel's window offsets (phase B)
   if constexpr (!GEMM) {
     const uint4* bot = (const uint4*)(ws + L.boff) + (long long)p * L_BRQ<R>::v;
@@ -619,12 +620,11 @@ __global__ void __launch_bounds__(GEMM ? 1024 : kBwdThreads) bwd_fast(const KP g
       const float gc = !POOL ? pair_value(gc4, k)
                        : (P >= VP ? ((o + k) >= (n0 + 1) * P ? gn1 : gn0) : gnfpm[(long long)b * N + fdivi(o + k, P)] * g.invP);
       if (M == NFP_COSINE) {
-        const float s = g.similarity ? oc : 1.f - oc;
-        const float sg = g.similarity ? gc : -gc;
+        const float s = g.osa * (oc - g.osb);   // out = osa * s + osb, osa = +-1
+        const float sg = g.osa * gc;
         AD[o + k] = make_float2(sg, sg * s);
       } else {
-        const float d = fabsf(oc);
-        CC[o + k] = d == 0.f ? 0.f : (g.similarity ? -gc : gc) * __builtin_amdgcn_rcpf(d);
+        CC[o + k] = dist_coef(g, gc, oc);
       }
     }
   };
@@ -643,9 +643,9 @@ __global__ void __launch_bounds__(GEMM ? 1024 : kBwdThreads) bwd_fast(const KP g
     }
   }
   if (M == NFP_COSINE && t < P) {
-    const float ip = __builtin_amdgcn_rcpf(fmaxf(nrm, g.eps));
+    const float ip = g.unit ? 1.f : __builtin_amdgcn_rcpf(fmaxf(nrm, g.eps));   // (DotProduct: no norm factors, no diagonal)
     ipn[t] = ip;
-    dfn[t] = nrm > 0.f ? -ip * __builtin_amdgcn_rcpf(nrm) : 0.f;
+    dfn[t] = (nrm > 0.f && !g.unit) ? -ip * __builtin_amdgcn_rcpf(nrm) : 0.f;
   }
   if constexpr (SYM) {  // slots before the centre whose pixel lies outside the image keep this 0 (Wt and Dt are adjacent)
     for (int i = t; i < (2 * P * K2) >> 2; i += T) ((float4*)Wt)[i] = make_float4(0.f, 0.f, 0.f, 0.f);

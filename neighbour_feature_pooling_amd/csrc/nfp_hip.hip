@@ -68,6 +68,13 @@ int make_kp(const nfp_desc* d, KP* g) {
   g->invNQ = 1.0f / (float)((g->P >> 2) > 0 ? (g->P >> 2) : 1);
   g->invPT = 1.0f / (float)((g->P & 3) > 0 ? (g->P & 3) : 1);
   g->inv_eps = 1.0f / g->eps;
+  // run-time constants of the hot-path kernels (nfp_common.h): products out = osa * s + osb, distances out = osa * sqrt(d2 * d2s)
+  const bool prod = d->measure == NFP_COSINE || d->measure == NFP_DOT;
+  g->unit = d->measure == NFP_DOT ? 1 : 0;
+  g->osa = prod ? (g->similarity ? 1.f : -1.f) : (g->similarity ? -1.f : 1.f);
+  g->osb = (d->measure == NFP_COSINE && !g->similarity) ? 1.f : 0.f;
+  g->d2s = d->measure == NFP_RMSE ? 1.0f / (float)d->C : 1.0f;
+  g->zero0 = d->measure == NFP_RMSE ? 0 : 1;
   // index arithmetic of the general kernels: coordinates in 15 bits, pair indices in 31
   if (d->H > 32767 || d->W > 32767 || (int64_t)g->P > (1 << 26) || (int64_t)g->N * g->O >= (1LL << 31) || d->B > 65535)
     return fail(NFP_E_UNSUPPORTED, "feature map [%d,%d,%d,%d] with k = %d exceeds the index range of the kernels", d->B,
@@ -327,7 +334,7 @@ bool fast_geometry(const KP& g) {
 bool fast_ok(const KP& g, const void* x, const void* gx) {
   if (force_generic()) return false;
   if (!fast_geometry(g) || (g.C & 3)) return false;
-  if (!(g.measure == NFP_COSINE || (g.measure == NFP_NORM && g.p == 2.f))) return false;
+  if (!hot_measure(g)) return false;
   const bool nhwc = g.sC == 1 && g.sW == g.C && g.sH == (long long)g.W * g.C;
   if (!g.contig && !nhwc) return false;
   if (!g.contig) {  // vector loads of 4 channels need natural alignment
@@ -394,7 +401,7 @@ int launch_fwd_band_t(KP g, const void* x, void* out, float* saved, hipStream_t 
   const size_t tail = (size_t)psm * (NF + 1) * 4 + (POOL ? (size_t)Win<R>::N * psm * 4 : 0);   // Tt (+ pooled-map staging)
   const size_t lds = slab + tail;
   if (lds > (size_t)kLdsMax) return kNotApplicable;
-  snprintf(g_variant, sizeof(g_variant), "fwd_band<R%s,%s,%s,%s%s>x%d", R == 12 ? "1+2" : (R == 1 ? "1" : "2"), M == NFP_COSINE ? "cos" : "l2",
+  snprintf(g_variant, sizeof(g_variant), "fwd_band<R%s,%s,%s,%s%s>x%d", R == 12 ? "1+2" : (R == 1 ? "1" : "2"), hot_name(g),
            BF ? "bf16" : "f32", NHWC ? "nhwc" : "nchw", POOL ? ",pool" : "", nb);
   return launch("fwd_band", fwd_band<R, M, BF, NHWC, POOL>, dim3(g.B, nb), dim3(T), lds, st, g, x, out, saved, g.ws,
                 rb, gap, nfpm);
@@ -451,7 +458,7 @@ int launch_bwd_fast_t(KP g, const void* x, const void* go, const void* out, cons
   const size_t lds = g.early ? fixed + pairs + slab : fixed + std::max(pairs, slab);
   if (lds > (size_t)kLdsMax) return kNotApplicable;  // tables + slab do not fit: the generic kernels serve it
   snprintf(g_variant, sizeof(g_variant), "bwd_fast<R%s,%s,%s,%s%s>", R == 12 ? "1+2" : (R == 1 ? "1" : "2"),
-           M == NFP_COSINE ? "cos" : "l2", BF ? "bf16" : "f32", NHWC ? "nhwc" : "nchw", POOL ? ",pool" : "");
+           hot_name(g), BF ? "bf16" : "f32", NHWC ? "nhwc" : "nchw", POOL ? ",pool" : "");
   return launch("bwd_fast", bwd_fast<R, M, BF, NHWC, POOL>, dim3(g.B, S), dim3(T), lds, st, g, x, go, out, saved, gx,
                 ggap, gnfpm, g.ws);
 }
@@ -463,6 +470,7 @@ template <int R, int M>
 int launch_fwd_gram(const KP& g, const void* x, void* out, float* saved, hipStream_t st, float* gap = nullptr,
                     float* nfpm = nullptr) {
   if (!mfma_enabled() || g.dtype != NFP_BF16 || (g.C & 15) || g.P > 512) return kNotApplicable;
+  if (g.unit || g.d2s != 1.f) return kNotApplicable;   // (DotProduct / RMSE: the vector kernels' run-time constants)
   if (!g.contig && (((uintptr_t)x & 15) || ((g.sB * 2) & 15))) return kNotApplicable;  // 16-byte fragment loads
   const int nt = (g.P + 31) / 32, D = std::min(nt - 1, (g.R * g.W + g.R + 31) / 32);
   const size_t tiles = (((size_t)nt * (D + 1) * 32 * kGramLd + 3) & ~(size_t)3) * 4;
@@ -472,7 +480,7 @@ int launch_fwd_gram(const KP& g, const void* x, void* out, float* saved, hipStre
   if (tiles + (size_t)g.P * 8 > (size_t)kLdsMax) return kNotApplicable;  // (the norm tables reuse the image's words)
   // the pooled variant takes its sums from the LDS image and stages the map values in it afterwards
   if (gap != nullptr && (tiles + image > (size_t)kLdsMax || image < (size_t)(2 + Win<R>::N) * g.P * 4)) return kNotApplicable;
-  snprintf(g_variant, sizeof(g_variant), "fwd_gram<R%d,%s,bf16,%s%s>", R, M == NFP_COSINE ? "cos" : "l2",
+  snprintf(g_variant, sizeof(g_variant), "fwd_gram<R%d,%s,bf16,%s%s>", R, hot_name(g),
            g.contig ? "nchw" : "nhwc", gap != nullptr ? ",pool" : "");
   if (g.contig)
     return launch("fwd_gram", fwd_gram<R, M, true, true>, dim3(g.B), dim3(1024), tiles + image, st, g, x, out, saved, D, g.ws,
@@ -526,7 +534,7 @@ int launch_bwd_gemm_t(KP g, const void* x, const void* go, const void* out, cons
   const size_t lds = fixed + std::max(bwd_pair_bytes(g, M, N), images);
   g.early = 0;
   if (lds > (size_t)kLdsMax) return kNotApplicable;
-  snprintf(g_variant, sizeof(g_variant), "bwd_fast<R%d,%s,bf16,%s,mfma%s>", R, M == NFP_COSINE ? "cos" : "l2",
+  snprintf(g_variant, sizeof(g_variant), "bwd_fast<R%d,%s,bf16,%s,mfma%s>", R, hot_name(g),
            NHWC ? "nhwc" : "nchw", POOL ? ",pool" : "");
   return launch("bwd_fast_mfma", bwd_fast<R, M, true, NHWC, POOL, true>, dim3(g.B, S), dim3(T), lds, st, g, x, go, out,
                 saved, gx, ggap, gnfpm, g.ws);
@@ -558,8 +566,10 @@ int launch_bwd_fast(const KP& g, const void* x, const void* go, const void* out,
 }  // namespace
 
 #ifdef NFP_STAMPS
+extern "C" int nfp_debug_set_stamp_buffer_tile(void* dev_ptr);
 extern "C" int nfp_debug_set_stamp_buffer(void* dev_ptr) {
   unsigned long long* p = (unsigned long long*)dev_ptr;
+  if (int rc = nfp_debug_set_stamp_buffer_tile(dev_ptr)) return rc;
   return hip_ok(hipMemcpyToSymbol(HIP_SYMBOL(nfp::nfp_stamp_buf), &p, sizeof(p)), "set stamp buffer");
 }
 #endif
@@ -618,20 +628,20 @@ int forward_impl(const nfp_desc* d, const void* x, void* out, float* saved, void
     if (g.ws == nullptr || !fast_ok(g, x, x))
       return fail(NFP_E_UNSUPPORTED, "multi-radius: cosine / L2 on maps of at most %d pixels, C %% 4 == 0, dense layout, "
                   "descriptor with a workspace", kBwdThreads);
-    const int rc = g.measure == NFP_COSINE ? launch_fwd_band<12, NFP_COSINE>(g, x, out, saved, st)
+    const int rc = hot_product(g) ? launch_fwd_band<12, NFP_COSINE>(g, x, out, saved, st)
                                            : launch_fwd_band<12, NFP_NORM>(g, x, out, saved, st);
     return rc == kNotApplicable ? fail(NFP_E_UNSUPPORTED, "multi-radius: the map does not fit the hot-path forward") : rc;
   }
   if (fast_ok(g, x, x)) {
     int rc;
-    if (g.measure == NFP_COSINE)
+    if (hot_product(g))
       rc = g.R == 1 ? launch_fwd_gram<1, NFP_COSINE>(g, x, out, saved, st)
                     : launch_fwd_gram<2, NFP_COSINE>(g, x, out, saved, st);
     else
       rc = g.R == 1 ? launch_fwd_gram<1, NFP_NORM>(g, x, out, saved, st)
                     : launch_fwd_gram<2, NFP_NORM>(g, x, out, saved, st);
     if (rc != kNotApplicable) return rc;
-    if (g.measure == NFP_COSINE)
+    if (hot_product(g))
       rc = g.R == 1 ? launch_fwd_band<1, NFP_COSINE>(g, x, out, saved, st)
                     : launch_fwd_band<2, NFP_COSINE>(g, x, out, saved, st);
     else
@@ -692,13 +702,13 @@ int backward_impl(const nfp_desc* d, const void* x, const void* grad_out, const 
     if (g.ws == nullptr || !fast_ok(g, x, grad_x))
       return fail(NFP_E_UNSUPPORTED, "multi-radius: cosine / L2 on maps of at most %d pixels, C %% 4 == 0, dense layout, "
                   "descriptor with a workspace", kBwdThreads);
-    const int rc = g.measure == NFP_COSINE ? launch_bwd_vec<12, NFP_COSINE>(g, x, grad_out, out, saved, grad_x, st)
+    const int rc = hot_product(g) ? launch_bwd_vec<12, NFP_COSINE>(g, x, grad_out, out, saved, grad_x, st)
                                            : launch_bwd_vec<12, NFP_NORM>(g, x, grad_out, out, saved, grad_x, st);
     return rc == kNotApplicable ? fail(NFP_E_UNSUPPORTED, "multi-radius: the map does not fit the hot-path backward") : rc;
   }
   if (g.ws != nullptr && fast_ok(g, x, grad_x)) {
     int rc;
-    if (g.measure == NFP_COSINE)
+    if (hot_product(g))
       rc = g.R == 1 ? launch_bwd_fast<1, NFP_COSINE>(g, x, grad_out, out, saved, grad_x, st)
                     : launch_bwd_fast<2, NFP_COSINE>(g, x, grad_out, out, saved, grad_x, st);
     else
@@ -905,14 +915,14 @@ static int pool_plan(const KP& g, bool backward) {
   void* fake = (void*)(uintptr_t)0x1000;
   int rc;
   if (!backward) {
-    if (g.measure == NFP_COSINE)
+    if (hot_product(g))
       rc = g.R == 1 ? pool_forward_rm<1, NFP_COSINE>(g, fake, fake, (float*)fake, nullptr, (float*)fake, (float*)fake)
                     : pool_forward_rm<2, NFP_COSINE>(g, fake, fake, (float*)fake, nullptr, (float*)fake, (float*)fake);
     else
       rc = g.R == 1 ? pool_forward_rm<1, NFP_NORM>(g, fake, fake, (float*)fake, nullptr, (float*)fake, (float*)fake)
                     : pool_forward_rm<2, NFP_NORM>(g, fake, fake, (float*)fake, nullptr, (float*)fake, (float*)fake);
   } else {
-    if (g.measure == NFP_COSINE)
+    if (hot_product(g))
       rc = g.R == 1 ? pool_backward_rm<1, NFP_COSINE>(g, fake, fake, (const float*)fake, fake, nullptr, (const float*)fake, (const float*)fake)
                     : pool_backward_rm<2, NFP_COSINE>(g, fake, fake, (const float*)fake, fake, nullptr, (const float*)fake, (const float*)fake);
     else
@@ -927,7 +937,7 @@ static int pool_plan(const KP& g, bool backward) {
 }
 
 static bool pool_measure_ok(const KP& g) {
-  return g.rs != 12 && (g.measure == NFP_COSINE || (g.measure == NFP_NORM && g.p == 2.f));
+  return g.rs != 12 && hot_measure(g);
 }
 
 int nfp_pool_supported(const nfp_desc* d) {
@@ -958,7 +968,7 @@ int nfp_pool_forward(const nfp_desc* d, const void* x, float* gap, float* nfpm, 
   if (g.B == 0) return NFP_OK;
   hipStream_t st = (hipStream_t)hip_stream;
   int rc;
-  if (g.measure == NFP_COSINE)
+  if (hot_product(g))
     rc = g.R == 1 ? pool_forward_rm<1, NFP_COSINE>(g, x, out_map, saved, st, gap, nfpm)
                   : pool_forward_rm<2, NFP_COSINE>(g, x, out_map, saved, st, gap, nfpm);
   else
@@ -977,7 +987,7 @@ int nfp_pool_backward(const nfp_desc* d, const void* x, const float* grad_gap, c
   if (g.B == 0) return NFP_OK;
   hipStream_t st = (hipStream_t)hip_stream;
   int rc;
-  if (g.measure == NFP_COSINE)
+  if (hot_product(g))
     rc = g.R == 1 ? pool_backward_rm<1, NFP_COSINE>(g, x, out_map, saved, grad_x, st, grad_gap, grad_nfpm)
                   : pool_backward_rm<2, NFP_COSINE>(g, x, out_map, saved, grad_x, st, grad_gap, grad_nfpm);
   else

@@ -18,14 +18,15 @@ namespace {
 bool tile_geometry(const KP& g) {
   if (g.stride != 1 || g.dil != 1 || g.pad != g.R || g.mode == NFP_PAD_CIRCULAR || g.rs == 12) return false;
   if (g.R != 1 && g.R != 2) return false;
-  if (g.W < 4 || (g.W + 2 * g.R) * (1 + 2 * g.R) > 1024) return false;     // a band of one row must fit the forward's threads
+  // a band of one row must fit the forward's threads
+  if (g.W < 4 || g.W < 2 * g.R + 2 || (g.W + 2 * g.R) * (1 + 2 * g.R) > 1024) return false;
   return g.W <= 512;                                                        // ... and the backward's
 }
 }  // namespace
 
 bool tile_ok(const KP& g, const void* x, const void* gx) {
   if (force_generic() || !tile_geometry(g) || (g.C & 3)) return false;
-  if (!(g.measure == NFP_COSINE || (g.measure == NFP_NORM && g.p == 2.f))) return false;
+  if (!hot_measure(g)) return false;
   const bool nhwc = g.sC == 1 && g.sW == g.C && g.sH == (long long)g.W * g.C;
   if (!g.contig && !nhwc) return false;
   const int es = g.dtype == NFP_F32 ? 4 : 2;
@@ -42,28 +43,30 @@ namespace {
 template <int R, int M, bool BF, bool NHWC, bool POOL = false>
 int launch_fwd_tile_t(KP g, const void* x, void* out, float* saved, hipStream_t st, float* part = nullptr, int* nb_out = nullptr) {
   constexpr int NF = Win<R>::NF, N = Win<R>::N;
-  const int Wp = g.W + 2 * R;
-  int rb_max = std::min(g.H, 1024 / Wp - 2 * R);
-  if (rb_max < 1) return kNotApplicable;
+  const int Wp = nfp::tile_row_stride(g.W, R), Wu = g.W + 2 * R;
   for (int attempt = 0; attempt < 2; ++attempt) {
+    // first choice: two workgroups per compute unit — half of LDS each; k = 3 runs in 64 registers (up to 1024 threads),
+    // k = 5 in up to 128 (at most 512 threads).  Second: one workgroup of up to 1024 threads and all of LDS.
     const size_t budget = attempt == 0 ? (size_t)NFP_TILE_LDS_KB * 1024 : (size_t)kLdsMax;
+    const int kCap = (R == 1 || attempt == 1) ? 1024 : 512;   // threads per workgroup
+    const int rb_max = std::min(g.H, kCap / Wu - 2 * R);
     for (int rb0 = rb_max; rb0 >= 1; --rb0) {
       int nb = std::max(ceil_div(g.H, rb0), std::min(g.H, ceil_div(NFP_TILE_WGS, g.B)));
       const int rb = ceil_div(g.H, nb);
       nb = ceil_div(g.H, rb);
-      const int rows = rb + 2 * R, npos = rows * Wp, nbp = rb * g.W;
+      const int rows = rb + 2 * R, npos = rows * Wp, npu = rows * Wu, nbp = rb * g.W;
       int lg = 0;
-      while (lg < 5 && (2 << lg) * npos <= 1024 && (2 << lg) <= g.C / 4) ++lg;
-      const int G = 1 << lg, T = ((G * npos + 63) / 64) * 64;
-      const int ppb = nfp::band_row_slots((npos + 3) & ~3, lg);
-      const size_t tail = (size_t)(NF + 1) * npos * 4 + (POOL ? (size_t)N * nbp * 4 : 0);
+      while (lg < 5 && (2 << lg) * npu <= kCap && (2 << lg) <= g.C / 4) ++lg;
+      const int G = 1 << lg, T = ((G * npu + 63) / 64) * 64;
+      const int ppb = nfp::band_row_slots(npos, lg);
+      const size_t tail = (size_t)(NF + 1) * npu * 4 + (POOL ? (size_t)N * nbp * 4 : 0);
       if (tail + (size_t)ppb * 16 > budget) continue;
       int ncq = (int)((budget - tail) / ((size_t)ppb * 16));
       if (NHWC) {
-        ncq = std::min(ncq, nfp::kTileKN * T / npos);
+        ncq = std::min(ncq, nfp::kFwdKN * T / npu);
       } else {
-        ncq = std::min(ncq, nfp::kTileKB * T / (rows * ((g.W + 3) / 4)));
-        ncq = std::min(ncq, nfp::kTileKR * T / (rows * 2 * R));
+        ncq = std::min(ncq, nfp::kFwdKB * T / (rows * ((g.W + 3) / 4)));
+        ncq = std::min(ncq, nfp::kFwdKR * T / (rows * 2 * R));
       }
       if (ncq < 1) continue;
       const int total = g.C / 4, nch = ceil_div(total, ncq);
@@ -73,7 +76,7 @@ int launch_fwd_tile_t(KP g, const void* x, void* out, float* saved, hipStream_t 
       const size_t lds = (size_t)(g.Cc / 4) * ppb * 16 + tail;
       nfp::TileGeo tg = {rb, nb, Wp, 1};
       if (nb_out) *nb_out = nb;
-      snprintf(g_variant, sizeof(g_variant), "fwd_tile<R%d,%s,%s,%s%s>x%d", R, M == NFP_COSINE ? "cos" : "l2", BF ? "bf16" : "f32",
+      snprintf(g_variant, sizeof(g_variant), "fwd_tile<R%d,%s,%s,%s%s>x%d", R, hot_name(g), BF ? "bf16" : "f32",
                NHWC ? "nhwc" : "nchw", POOL ? ",pool" : "", nb);
       return launch("fwd_tile", fwd_tile<R, M, BF, NHWC, POOL>, dim3((unsigned)(g.B * nb)), dim3(T), lds, st, g, tg, x, out, saved,
                     part);
@@ -86,7 +89,7 @@ template <int R, int M, bool BF, bool NHWC, bool POOL = false>
 int launch_bwd_tile_t(KP g, const void* x, const void* go, const void* out, const float* saved, void* gx, hipStream_t st,
                       const float* ggap = nullptr, const float* gnfpm = nullptr) {
   constexpr int N = Win<R>::N, K2 = Win<R>::K2;
-  const int Wp = g.W + 2 * R, pvw = M == NFP_COSINE ? 2 : 1;
+  const int Wp = nfp::tile_row_stride(g.W, R), Wu = g.W + 2 * R, pvw = M == NFP_COSINE ? 2 : 1;
   const int rb_max = std::min(g.H, 512 / g.W);
   if (rb_max < 1) return kNotApplicable;
   for (int attempt = 0; attempt < 2; ++attempt) {
@@ -95,10 +98,10 @@ int launch_bwd_tile_t(KP g, const void* x, const void* go, const void* out, cons
       int nb = std::max(ceil_div(g.H, rb0), std::min(g.H, ceil_div(NFP_TILE_WGS, g.B)));
       const int rb = ceil_div(g.H, nb);
       nb = ceil_div(g.H, rb);
-      const int rows = rb + 2 * R, npos = rows * Wp, nbp = rb * g.W, npA = std::min(g.H, rows) * g.W;
-      const size_t fixed = ((size_t)(nbp * K2 + npos + nbp) * 4 + 15) & ~(size_t)15;
+      const int rows = rb + 2 * R, npos = rows * Wp, npu = rows * Wu, nbp = rb * g.W, npA = std::min(g.H, rows) * g.W;
+      const size_t fixed = ((size_t)(nbp * K2 + npu + nbp) * 4 + 15) & ~(size_t)15;
       const size_t pv = (size_t)N * npA * pvw * 4;
-      const int ppb = ((npos + 3) & ~3) | 1;
+      const int ppb = npos | 1;
       if (fixed + std::max(pv, (size_t)ppb * 16) > budget) continue;
       // channel blocks: enough workgroups to fill the chip when images x bands do not
       int S = ceil_div(NFP_TILE_WGS, g.B * nb);
@@ -110,10 +113,10 @@ int launch_bwd_tile_t(KP g, const void* x, const void* go, const void* out, cons
       const int T = ((nbp * g.G + 63) / 64) * 64;
       int ncq = (int)((budget - fixed) / ((size_t)ppb * 16));
       if (NHWC) {
-        ncq = std::min(ncq, nfp::kTileKN * T / npos);
+        ncq = std::min(ncq, nfp::kBwdKN * T / npu);
       } else {
-        ncq = std::min(ncq, nfp::kTileKB * T / (rows * ((g.W + 3) / 4)));
-        ncq = std::min(ncq, nfp::kTileKR * T / (rows * 2 * R));
+        ncq = std::min(ncq, nfp::kBwdKB * T / (rows * ((g.W + 3) / 4)));
+        ncq = std::min(ncq, nfp::kBwdKR * T / (rows * 2 * R));
       }
       if (ncq < 1) continue;
       const int total = g.Cwg / 4, nch = ceil_div(total, ncq);
@@ -121,7 +124,7 @@ int launch_bwd_tile_t(KP g, const void* x, const void* go, const void* out, cons
       g.G = even_groups(g.Cc / 4, g.G);
       const size_t lds = fixed + std::max(pv, (size_t)(g.Cc / 4) * ppb * 16);
       nfp::TileGeo tg = {rb, nb, Wp, S};
-      snprintf(g_variant, sizeof(g_variant), "bwd_tile<R%d,%s,%s,%s%s>x%d", R, M == NFP_COSINE ? "cos" : "l2", BF ? "bf16" : "f32",
+      snprintf(g_variant, sizeof(g_variant), "bwd_tile<R%d,%s,%s,%s%s>x%d", R, hot_name(g), BF ? "bf16" : "f32",
                NHWC ? "nhwc" : "nchw", POOL ? ",pool" : "", nb);
       return launch("bwd_tile", bwd_tile<R, M, BF, NHWC, POOL>, dim3((unsigned)(g.B * nb * S)), dim3(T), lds, st, g, tg, x, go, out,
                     saved, gx, ggap, gnfpm);
@@ -152,7 +155,7 @@ int bwd_rm(const KP& g, const void* x, const void* go, const void* out, const fl
 
 int tile_forward(const KP& g, const void* x, void* out, float* saved, hipStream_t st, bool pool, float* part, int* nb) {
   if (!tile_ok(g, x, x)) return kNotApplicable;
-  const bool cosv = g.measure == NFP_COSINE;
+  const bool cosv = hot_product(g);
   if (pool) {
     if (cosv) return g.R == 1 ? fwd_rm<1, NFP_COSINE, true>(g, x, out, saved, st, part, nb) : fwd_rm<2, NFP_COSINE, true>(g, x, out, saved, st, part, nb);
     return g.R == 1 ? fwd_rm<1, NFP_NORM, true>(g, x, out, saved, st, part, nb) : fwd_rm<2, NFP_NORM, true>(g, x, out, saved, st, part, nb);
@@ -164,7 +167,7 @@ int tile_forward(const KP& g, const void* x, void* out, float* saved, hipStream_
 int tile_backward(const KP& g, const void* x, const void* go, const void* out, const float* saved, void* gx, hipStream_t st,
                   bool pool, const float* ggap, const float* gnfpm) {
   if (!tile_ok(g, x, gx)) return kNotApplicable;
-  const bool cosv = g.measure == NFP_COSINE;
+  const bool cosv = hot_product(g);
   if (pool) {
     if (cosv) return g.R == 1 ? bwd_rm<1, NFP_COSINE, true>(g, x, go, out, saved, gx, st, ggap, gnfpm) : bwd_rm<2, NFP_COSINE, true>(g, x, go, out, saved, gx, st, ggap, gnfpm);
     return g.R == 1 ? bwd_rm<1, NFP_NORM, true>(g, x, go, out, saved, gx, st, ggap, gnfpm) : bwd_rm<2, NFP_NORM, true>(g, x, go, out, saved, gx, st, ggap, gnfpm);
@@ -180,3 +183,11 @@ int tile_pool_fold(const KP& g, const float* part, float* gap, float* nfpm, int 
 }
 
 }  // namespace nfp_host
+
+#ifdef NFP_STAMPS
+// (every translation unit has its own copy of the device-side stamp pointer)
+extern "C" int nfp_debug_set_stamp_buffer_tile(void* dev_ptr) {
+  unsigned long long* p = (unsigned long long*)dev_ptr;
+  return hipMemcpyToSymbol(HIP_SYMBOL(nfp::nfp_stamp_buf), &p, sizeof(p)) == hipSuccess ? 0 : -3;
+}
+#endif

@@ -22,7 +22,7 @@ def _cases():
            (1, 36, 33, 31, 2, "norm", "reflect"), (300, 8, 24, 24, 1, "cosine", "reflect"),
            (2, 260, 26, 26, 1, "cosine", "reflect"),     # channel chunks
            (1, 512, 23, 23, 1, "norm", "reflect"),       # one image: channel blocks in the backward
-           (2, 16, 6, 100, 2, "cosine", "reflect"), (2, 16, 200, 5, 2, "cosine", "replicate"), (1, 4, 3, 180, 1, "norm", "zeros")]
+           (2, 16, 6, 100, 2, "cosine", "reflect"), (2, 16, 200, 6, 2, "cosine", "replicate"), (1, 4, 3, 180, 1, "norm", "zeros")]
     return cs
 
 
@@ -99,3 +99,44 @@ def test_tile_kernels_dissimilarity_and_norm_quirk():
     g2, = torch.autograd.grad(r, x64, go.double())
     assert rel_err(o.detach().cpu().numpy(), r.detach().cpu().numpy()) <= TOL
     assert rel_err(g1.cpu().numpy(), g2.cpu().numpy()) <= TOL
+
+
+@pytest.mark.parametrize("B,C,H,W,R,meas", [(3, 16, 112, 112, 1, "cosine"), (5, 24, 56, 56, 1, "norm"), (2, 128, 28, 28, 1, "cosine"),
+                                            (2, 40, 28, 28, 2, "cosine"), (2, 8, 30, 37, 1, "norm")])
+@pytest.mark.parametrize("layout,dtype", [("nchw", torch.float32), ("nhwc", torch.float32), ("nhwc", torch.bfloat16)])
+def test_fused_pooling_tail_on_large_maps(B, C, H, W, R, meas, layout, dtype):
+    """models/texture_pooling.py:249-252 averages every MultiStage map at once: GAP(x) and GAP(NFP(x)) from the row-band
+    kernels (per-band partial sums joined by pool_fold), forward and backward, against the float64 formulation."""
+    from neighbour_feature_pooling_amd import NFPPooling, _abi
+    from neighbour_feature_pooling_amd._host import nfp_host
+    from neighbour_feature_pooling_amd.functional import nfp_pool, nfp_pool_fused_ok
+    from neighbour_feature_pooling_amd.synth import feature_map
+    dev = torch.device("cuda:0")
+    ctor = dict(R=R, measure=meas, padding=R)
+    if meas == "norm":
+        ctor["p"] = 2
+    m = NFPPooling(C, **ctor)
+    x = torch.from_numpy(feature_map((B, C, H, W), H + 2 * W + C)).to(dev).to(dtype)
+    if layout == "nhwc":
+        x = x.contiguous(memory_format=torch.channels_last)
+    x.requires_grad_(True)
+    assert nfp_pool_fused_ok(x, m.config)
+    L = _abi.load()
+    n0 = L.nfp_launch_count()
+    gap, nfpm = nfp_pool(x, m.config)
+    fv = L.nfp_last_variant().decode()
+    wg = torch.from_numpy(feature_map((B, C), 11)).to(dev)
+    wn = torch.from_numpy(feature_map((B, m.out_channels), 12)).to(dev)
+    (gx,) = torch.autograd.grad((gap * wg).sum() + (nfpm * wn).sum(), x)
+    torch.cuda.synchronize()
+    bv = L.nfp_last_variant().decode()
+    assert L.nfp_launch_count() == n0 + 3, "forward band kernel + fold, one backward kernel"
+    assert fv.startswith("fwd_tile<") and fv.endswith(",pool>x%s+pool_fold" % fv.split(">x")[1].split("+")[0]) and ",pool>" in bv, (fv, bv)
+    x64 = x.detach().double().contiguous().requires_grad_(True)
+    ref = nfp_host(x64, m.config)
+    rg, rn = x64.mean((2, 3)), ref.mean((2, 3))
+    (gref,) = torch.autograd.grad((rg * wg.double()).sum() + (rn * wn.double()).sum(), x64)
+    tol_o, tol_g = (1e-5, 1e-5) if dtype == torch.float32 else (1e-2, 2e-2)
+    assert rel_err(gap.detach().cpu().numpy(), rg.detach().cpu().numpy()) <= tol_o
+    assert rel_err(nfpm.detach().cpu().numpy(), rn.detach().cpu().numpy()) <= tol_o
+    assert rel_err(gx.float().cpu().numpy(), gref.cpu().numpy()) <= tol_g
