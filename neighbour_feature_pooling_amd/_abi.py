@@ -72,8 +72,9 @@ def load():
     L.nfp_forward.argtypes = [dp, vp, vp, vp, vp]
     L.nfp_backward.argtypes = [dp, vp, vp, vp, vp, vp, vp]
     L.nfp_pool_supported.argtypes = [dp]
-    L.nfp_pool_saved_floats.argtypes = [dp]
-    L.nfp_pool_saved_floats.restype = ctypes.c_int64
+    if hasattr(L, "nfp_pool_saved_floats"):     # (absent only from an older library loaded for an A/B run)
+        L.nfp_pool_saved_floats.argtypes = [dp]
+        L.nfp_pool_saved_floats.restype = ctypes.c_int64
     L.nfp_pool_forward.argtypes = [dp, vp, vp, vp, vp, vp, vp]
     L.nfp_pool_backward.argtypes = [dp, vp, vp, vp, vp, vp, vp, vp]
     if L.nfp_abi_version() != ABI_VERSION:

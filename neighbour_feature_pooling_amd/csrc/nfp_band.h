@@ -46,10 +46,13 @@ struct FoffQ {
 // (template parameter R of fwd_band: the radius SPEC of nfp_tables.h::Win — 1, 2, or 12 for radii 1 and 2 together;
 // the window radius itself is g.R)
 
-// POOL = the fused tail of models/NFP_Pooling.py:27-31 (one band = the whole image): besides the neighbour maps the
-// same pass emits  gap[b,c] = mean over pixels of x[b,c]  (AdaptiveAvgPool2d(1), NFP_Pooling.py:27) and
-// nfpm[b,n] = mean over pixels of out[b,n]  (adaptive_avg_pool2d of the NFP maps, NFP_Pooling.py:31), both float32,
-// summed in a fixed order, for either layout and storage type (the sums are taken from the float32 LDS slab).
+// POOL = the fused tail of models/NFP_Pooling.py:27-31: besides the neighbour maps the same pass emits
+// gap[b,c] = mean over pixels of x[b,c]  (AdaptiveAvgPool2d(1), NFP_Pooling.py:27) and  nfpm[b,n] = mean over pixels of
+// out[b,n]  (adaptive_avg_pool2d of the NFP maps, NFP_Pooling.py:31), both float32, summed in a fixed order, for either
+// layout and storage type (the sums are taken from the float32 LDS slab).  One band per image writes the two means
+// itself; with several bands per image (small batches: round 2 ran the pooled forward on one workgroup per image, 64 of
+// 256 compute units at the headline shape, 8.1 us against 4.85 us for the plain forward) every band writes its share of
+// the sums to row (b, band) of a scratch passed in `gap` and nfp_tile.h::pool_fold joins the bands in a fixed order.
 //
 // Thread maps.  Channel sums: thread t = lp * G + gl — the G channel groups of a pixel are ADJACENT LANES (G a power
 // of two <= 32, g.G; g.Tc = log2 G), so the groups' partial sums are joined by a fixed DPP tree inside the wavefront:
@@ -133,10 +136,19 @@ __global__ void __launch_bounds__(1024) fwd_band(const KP g, const void* __restr
           const int ps = min(4 * pq, P - 4);
           float4* d = slab + cq * Ppb - base;
           // (the overlapped last block of an image with P % 4 != 0 may start below the band's slot origin: those pixels
-          // belong to the band above and have no slot here)
-          if (ps >= base) d[swz(ps)] = make_float4(blk[r][0].x, blk[r][1].x, blk[r][2].x, blk[r][3].x);
-          if (ps + 1 >= base) d[swz(ps + 1)] = make_float4(blk[r][0].y, blk[r][1].y, blk[r][2].y, blk[r][3].y);
-          if (ps + 2 >= base) d[swz(ps + 2)] = make_float4(blk[r][0].z, blk[r][1].z, blk[r][2].z, blk[r][3].z);
+          // belong to the band above and have no slot here.  Their values go to the slot of ps + 3 instead, which the
+          // last store below then overwrites with its own value — a select on the address, not a predicated store: three
+          // predicates cost 24 registers and a spill in this kernel)
+          const int s3 = swz(ps + 3);
+#ifdef NFP_BAND_NO_GUARD   // (A/B: round 2's unguarded stores)
+          d[swz(ps)] = make_float4(blk[r][0].x, blk[r][1].x, blk[r][2].x, blk[r][3].x);
+          d[swz(ps + 1)] = make_float4(blk[r][0].y, blk[r][1].y, blk[r][2].y, blk[r][3].y);
+          d[swz(ps + 2)] = make_float4(blk[r][0].z, blk[r][1].z, blk[r][2].z, blk[r][3].z);
+#else
+          d[ps >= base ? swz(ps) : s3] = make_float4(blk[r][0].x, blk[r][1].x, blk[r][2].x, blk[r][3].x);
+          d[ps + 1 >= base ? swz(ps + 1) : s3] = make_float4(blk[r][0].y, blk[r][1].y, blk[r][2].y, blk[r][3].y);
+          d[ps + 2 >= base ? swz(ps + 2) : s3] = make_float4(blk[r][0].z, blk[r][1].z, blk[r][2].z, blk[r][3].z);
+#endif
           d[swz(ps + 3)] = make_float4(blk[r][0].w, blk[r][1].w, blk[r][2].w, blk[r][3].w);
         }
       }
@@ -168,12 +180,16 @@ __global__ void __launch_bounds__(1024) fwd_band(const KP g, const void* __restr
     __syncthreads();
     if (c0 == 0) NFP_STAMP(2);
     if constexpr (POOL) {
-      // channel means of this chunk: four adjacent lanes per channel quad, lane `part` sums pixels part, part + 4, ...;
-      // joined by a fixed xor tree
+      // channel sums of this chunk over the band's OWN pixels: four adjacent lanes per channel quad, lane `part` sums
+      // pixels p0 + part, p0 + part + 4, ...; joined by a fixed xor tree.  One band per image: the mean goes straight to
+      // gap[b][c]; several bands: the band's sum goes to its row of the scratch (pool_fold joins the bands in order).
+      const int nbands = gridDim.y;
+      float* gdst = nbands == 1 ? gap + (long long)b * g.C : gap + ((long long)b * nbands + band) * (g.C + N);
+      const float gscale = nbands == 1 ? g.invP : 1.f;
       for (int i0 = 0; i0 < ncq * 4; i0 += T) {
         const int i = i0 + t, cq = min(i >> 2, ncq - 1), part = i & 3;
         float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int pp = part; pp < P; pp += 4) {
+        for (int pp = p0 + part; pp < po; pp += 4) {
           const float4 v = slab[cq * Ppb + swz(pp) - base];
           s4.x += v.x;
           s4.y += v.y;
@@ -185,8 +201,7 @@ __global__ void __launch_bounds__(1024) fwd_band(const KP g, const void* __restr
         s4.z = group_sum(s4.z, 4);
         s4.w = group_sum(s4.w, 4);
         if (i < ncq * 4 && part == 0)
-          *(float4*)(gap + (long long)b * g.C + c0 + 4 * cq) =
-              make_float4(s4.x * g.invP, s4.y * g.invP, s4.z * g.invP, s4.w * g.invP);
+          *(float4*)(gdst + c0 + 4 * cq) = make_float4(s4.x * gscale, s4.y * gscale, s4.z * gscale, s4.w * gscale);
       }
     }
     if (active) {
@@ -226,7 +241,7 @@ __global__ void __launch_bounds__(1024) fwd_band(const KP g, const void* __restr
   if (glf < Gn) {
     void* ob = (char*)out + (long long)b * N * P * ES;
     const float n2p = n2[lpf];
-    const float ip = g.unit ? 1.f : inv_norm(n2p, g.inv_eps);
+    const float ip = unit_or(g, inv_norm(n2p, g.inv_eps));
     for (int n = glf; n < N; n += Gn) {
       const uint32_t e = n == glf ? fte : ftt[n * P + pf];
       const int kind = (int)(e >> 22), pix = (int)((e >> 9) & 511u), fi = (int)((e >> 18) & 15u);
@@ -236,7 +251,7 @@ __global__ void __launch_bounds__(1024) fwd_band(const KP g, const void* __restr
         const float n2q = n2[q - p0];
         float v;
         if (M == NFP_COSINE) {
-          const float s = kind == 2 ? 0.f : (kind == 1 ? n2p : pairv) * ip * (g.unit ? 1.f : inv_norm(n2q, g.inv_eps));
+          const float s = kind == 2 ? 0.f : (kind == 1 ? n2p : pairv) * ip * unit_or(g, inv_norm(n2q, g.inv_eps));
           v = fin_prod(g, s);
         } else {
           float d2;
@@ -248,20 +263,28 @@ __global__ void __launch_bounds__(1024) fwd_band(const KP g, const void* __restr
         }
         stx(ob, n * P + pf, v, BF ? NFP_BF16 : NFP_F32);
         if constexpr (POOL) Tt[NV + n * Ps + lpf] = v;  // vm[n][p], behind the half-stencil table
+      } else if constexpr (POOL) {
+        Tt[NV + n * Ps + lpf] = 0.f;                    // (an output another band writes: not part of this band's sum)
       }
     }
     if (M == NFP_COSINE && !g.unit && saved != nullptr && glf == 0 && pf < po) saved[(long long)b * P + pf] = __builtin_amdgcn_sqrtf(n2p);
   }
   if constexpr (POOL) {
     __syncthreads();
-    // wave w reduces map n = w, w + nwaves, ...: lane-strided partial sums, then a fixed shuffle tree
+    // wave w reduces map n = w, w + nwaves, ...: lane-strided partial sums over the outputs THIS band wrote, then a
+    // fixed shuffle tree
     const float* vm = Tt + NV;
-    const int lane = t & 63, wv = t >> 6, nw = T >> 6;
+    const int lane = t & 63, wv = t >> 6, nw = T >> 6, nbands = gridDim.y;
     for (int n = wv; n < N; n += nw) {
       float sacc = 0.f;
-      for (int i = lane; i < P; i += 64) sacc += vm[n * Ps + i];
+      for (int i = lane; i < Ps; i += 64) sacc += vm[n * Ps + i];
       for (int m = 32; m >= 1; m >>= 1) sacc += __shfl_xor(sacc, m);
-      if (lane == 0) nfpm[(long long)b * N + n] = sacc * g.invP;
+      if (lane == 0) {
+        if (nbands == 1)
+          nfpm[(long long)b * N + n] = sacc * g.invP;
+        else
+          gap[((long long)b * nbands + band) * (g.C + N) + g.C + n] = sacc;
+      }
     }
   }
   NFP_STAMP(5);

@@ -44,7 +44,10 @@ struct KP {
   //                                         subgradient at distance 0 (zero0 = 0: torch's sqrt gives inf * 0 = NaN there)
   float osa, osb, d2s;
   int unit, zero0;
+  float uf, nuf;   // (float)unit and 1 - (float)unit: "1 if unit else v" as fmaf(v, nuf, uf) — exact, and not a branch on a
+                   // wave-uniform flag in the latency-critical finalize
 };
+__device__ __forceinline__ float unit_or(const KP& g, float v) { return fmaf(v, g.nuf, g.uf); }
 __device__ __forceinline__ float fin_prod(const KP& g, float s) { return fmaf(g.osa, s, g.osb); }
 __device__ __forceinline__ float fin_dist(const KP& g, float d2) { return g.osa * __builtin_amdgcn_sqrtf(d2 * g.d2s); }
 // per-pair backward scalar of a distance map: d out / d (a - b)[c] = coefficient * (a - b)[c]

@@ -643,9 +643,9 @@ __global__ void __launch_bounds__(GEMM ? 1024 : kBwdThreads) bwd_fast(const KP g
     }
   }
   if (M == NFP_COSINE && t < P) {
-    const float ip = g.unit ? 1.f : __builtin_amdgcn_rcpf(fmaxf(nrm, g.eps));   // (DotProduct: no norm factors, no diagonal)
+    const float ip = unit_or(g, __builtin_amdgcn_rcpf(fmaxf(nrm, g.eps)));   // (DotProduct: no norm factors, no diagonal)
     ipn[t] = ip;
-    dfn[t] = (nrm > 0.f && !g.unit) ? -ip * __builtin_amdgcn_rcpf(nrm) : 0.f;
+    dfn[t] = nrm > 0.f ? -g.nuf * ip * __builtin_amdgcn_rcpf(nrm) : 0.f;
   }
   if constexpr (SYM) {  // slots before the centre whose pixel lies outside the image keep this 0 (Wt and Dt are adjacent)
     for (int i = t; i < (2 * P * K2) >> 2; i += T) ((float4*)Wt)[i] = make_float4(0.f, 0.f, 0.f, 0.f);

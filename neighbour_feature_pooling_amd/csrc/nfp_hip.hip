@@ -71,6 +71,8 @@ int make_kp(const nfp_desc* d, KP* g) {
   // run-time constants of the hot-path kernels (nfp_common.h): products out = osa * s + osb, distances out = osa * sqrt(d2 * d2s)
   const bool prod = d->measure == NFP_COSINE || d->measure == NFP_DOT;
   g->unit = d->measure == NFP_DOT ? 1 : 0;
+  g->uf = (float)g->unit;
+  g->nuf = 1.0f - g->uf;
   g->osa = prod ? (g->similarity ? 1.f : -1.f) : (g->similarity ? -1.f : 1.f);
   g->osb = (d->measure == NFP_COSINE && !g->similarity) ? 1.f : 0.f;
   g->d2s = d->measure == NFP_RMSE ? 1.0f / (float)d->C : 1.0f;
@@ -368,13 +370,21 @@ int chunk_channels(const KP& g, int total, int T, int G, bool nhwc, int budget) 
 #endif
 template <int R, int M, bool BF, bool NHWC, bool POOL = false>
 int launch_fwd_band_t(KP g, const void* x, void* out, float* saved, hipStream_t st, float* gap = nullptr,
-                      float* nfpm = nullptr) {
+                      float* nfpm = nullptr, float* part = nullptr, int* nb_out = nullptr) {
   constexpr int NF = Win<R>::NF;
   int nb = std::min(g.H, (NFP_BAND_WGS + g.B - 1) / g.B);   // bands per image so that >= NFP_BAND_WGS workgroups exist
   // two workgroups per CU overlap each other's load and sum phases — worth it while a band's R halo rows stay a small
   // part of what it stages (14x14, k = 3 at B = 256: 12.8 -> 10.8 us; not 7x7: 7.3 -> 8.2 us)
   nb = std::max(nb, std::min((2 * NFP_BAND_WGS + g.B - 1) / g.B, g.H / (6 * g.R)));
-  if (POOL) nb = 1;   // the pooled outputs are sums over the whole image: one workgroup per image, nothing to combine
+  // The pooled outputs are sums over the whole image.  One workgroup per image writes them itself; several bands per image
+  // write partial sums that a second launch (pool_fold) joins.  Measured at [64,512,7,7] (profiles/r03_i_fused_callers.jsonl):
+  // four bands + fold 9.5 us against 8.1 us for one band — the second launch costs more than the bands save — so the table
+  // kernels keep one band (-DNFP_POOL_BANDS=1 builds the other arm; the row-band kernels of nfp_tile.h, whose maps do not
+  // fit one workgroup, always fold).
+#ifndef NFP_POOL_BANDS
+#define NFP_POOL_BANDS 0
+#endif
+  if (POOL && (part == nullptr || !NFP_POOL_BANDS)) nb = 1;
   const int rb = (g.H + nb - 1) / nb;
   nb = (g.H + rb - 1) / rb;
   const int psm = std::min(g.P, (rb + g.R) * g.W);          // most pixels a band stages
@@ -403,8 +413,10 @@ int launch_fwd_band_t(KP g, const void* x, void* out, float* saved, hipStream_t 
   if (lds > (size_t)kLdsMax) return kNotApplicable;
   snprintf(g_variant, sizeof(g_variant), "fwd_band<R%s,%s,%s,%s%s>x%d", R == 12 ? "1+2" : (R == 1 ? "1" : "2"), hot_name(g),
            BF ? "bf16" : "f32", NHWC ? "nhwc" : "nchw", POOL ? ",pool" : "", nb);
+  if (nb_out) *nb_out = nb;
+  // (pooled, several bands: the bands' partial sums go to `part`; the caller folds them — pool_forward_rm)
   return launch("fwd_band", fwd_band<R, M, BF, NHWC, POOL>, dim3(g.B, nb), dim3(T), lds, st, g, x, out, saved, g.ws,
-                rb, gap, nfpm);
+                rb, (POOL && nb > 1) ? part : gap, nfpm);
 }
 
 template <int R, int M>
@@ -632,6 +644,8 @@ int forward_impl(const nfp_desc* d, const void* x, void* out, float* saved, void
                                            : launch_fwd_band<12, NFP_NORM>(g, x, out, saved, st);
     return rc == kNotApplicable ? fail(NFP_E_UNSUPPORTED, "multi-radius: the map does not fit the hot-path forward") : rc;
   }
+  if (g_sw.tile_first.load(std::memory_order_relaxed))
+    if (int rc = tile_forward(g, x, out, saved, st, false, nullptr, nullptr); rc != kNotApplicable) return rc;
   if (fast_ok(g, x, x)) {
     int rc;
     if (hot_product(g))
@@ -706,6 +720,8 @@ int backward_impl(const nfp_desc* d, const void* x, const void* grad_out, const 
                                            : launch_bwd_vec<12, NFP_NORM>(g, x, grad_out, out, saved, grad_x, st);
     return rc == kNotApplicable ? fail(NFP_E_UNSUPPORTED, "multi-radius: the map does not fit the hot-path backward") : rc;
   }
+  if (g_sw.tile_first.load(std::memory_order_relaxed))
+    if (int rc = tile_backward(g, x, grad_out, out, saved, grad_x, st, false, nullptr, nullptr); rc != kNotApplicable) return rc;
   if (g.ws != nullptr && fast_ok(g, x, grad_x)) {
     int rc;
     if (hot_product(g))
@@ -766,10 +782,18 @@ int pool_forward_rm(const KP& g, const void* x, void* out_map, float* saved, hip
       rc = launch_fwd_gram<R, M>(g, x, out_map, saved, st, gap, nfpm);
       if (rc != kNotApplicable) return rc;
     }
-    if (bf) rc = nhwc ? launch_fwd_band_t<R, M, true, true, true>(g, x, out_map, saved, st, gap, nfpm)
-                      : launch_fwd_band_t<R, M, true, false, true>(g, x, out_map, saved, st, gap, nfpm);
-    else rc = nhwc ? launch_fwd_band_t<R, M, false, true, true>(g, x, out_map, saved, st, gap, nfpm)
-                   : launch_fwd_band_t<R, M, false, false, true>(g, x, out_map, saved, st, gap, nfpm);
+    // row bands at small batches: each band's share of the pooled sums goes to the scratch behind the norms
+    float* part = saved != nullptr ? saved + (long long)stats_of(g.measure) * g.B * g.P : nullptr;
+    int nb = 1;
+    if (bf) rc = nhwc ? launch_fwd_band_t<R, M, true, true, true>(g, x, out_map, saved, st, gap, nfpm, part, &nb)
+                      : launch_fwd_band_t<R, M, true, false, true>(g, x, out_map, saved, st, gap, nfpm, part, &nb);
+    else rc = nhwc ? launch_fwd_band_t<R, M, false, true, true>(g, x, out_map, saved, st, gap, nfpm, part, &nb)
+                   : launch_fwd_band_t<R, M, false, false, true>(g, x, out_map, saved, st, gap, nfpm, part, &nb);
+    if (rc == NFP_OK && nb > 1) {
+      t_pool_scratch = (long long)g.B * nb * (g.C + g.N);
+      strncat(g_variant, "+pool_fold", sizeof(g_variant) - strlen(g_variant) - 1);
+      return tile_pool_fold(g, part, gap, nfpm, nb, st);
+    }
     if (rc != kNotApplicable) return rc;
   }
   if (!tile_ok(g, x, x)) return kNotApplicable;

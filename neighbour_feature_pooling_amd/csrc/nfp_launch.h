@@ -39,7 +39,7 @@ inline void publish_variant() {
 // Test / A-B switches, read from the environment ONCE when the library is loaded (and again only when a test
 // calls nfp_reload_env): the launch path itself never reads it.
 struct Switches {
-  std::atomic<int> fwd_scalar{0}, bwd_atomic{0}, bwd_bands{0}, force_generic{0}, mfma{1};
+  std::atomic<int> fwd_scalar{0}, bwd_atomic{0}, bwd_bands{0}, force_generic{0}, mfma{1}, tile_first{0};
 };
 inline Switches g_sw;
 #ifndef NFP_MFMA_DEFAULT
@@ -54,6 +54,7 @@ inline void read_env() {
   g_sw.bwd_atomic = flag("NFP_BWD_ATOMIC", 0);
   g_sw.force_generic = flag("NFP_FORCE_GENERIC", 0);
   g_sw.mfma = flag("NFP_MFMA", NFP_MFMA_DEFAULT);
+  g_sw.tile_first = flag("NFP_TILE_FIRST", 0);   // A/B: the row-band kernels of nfp_tile.h also for maps the table kernels serve
   const char* e = getenv("NFP_BWD_BANDS");
   g_sw.bwd_bands = e ? atoi(e) : 0;
 }

@@ -308,7 +308,7 @@ __global__ void __launch_bounds__(1024, (R == 1 ? 8 : 4)) fwd_tile(const KP g, c
     const int p = (bd.y0 + yl) * W + xl;
     void* ob = (char*)out + (long long)b * N * P * ES;
     const float n2p = n2[pv];
-    const float ip = g.unit ? 1.f : inv_norm(n2p, g.inv_eps);
+    const float ip = unit_or(g, inv_norm(n2p, g.inv_eps));
     auto one = [&](int n) {
       int dy, dx;
       tap_offset<R>(n, dy, dx);
@@ -319,7 +319,7 @@ __global__ void __launch_bounds__(1024, (R == 1 ? 8 : 4)) fwd_tile(const KP g, c
       const float n2q = n2[qv];
       float val;
       if (M == NFP_COSINE) {
-        const float s = pairv * ip * (g.unit ? 1.f : inv_norm(n2q, g.inv_eps));
+        const float s = pairv * ip * unit_or(g, inv_norm(n2q, g.inv_eps));
         val = fin_prod(g, s);
       } else {
         val = fin_dist(g, g.diff ? pairv : n2q);  // 'Norm' quirk (nfp.py:74 vs 85): |neighbour|
@@ -439,10 +439,10 @@ __global__ void __launch_bounds__(512) bwd_tile(const KP g, const TileGeo tg, co
       const int vy = fdivi(v, Wu), vx = v - vy * Wu;
       const int sy = fo.y(bd.y0 - R + vy, H), sx = fo.x(vx - R, W);
       const float nrm = (sy | sx) < 0 ? 0.f : nrm_raw;
-      const float ip = g.unit ? 1.f : __builtin_amdgcn_rcpf(fmaxf(nrm, g.eps));   // (DotProduct: no norm factors, no diagonal)
+      const float ip = unit_or(g, __builtin_amdgcn_rcpf(fmaxf(nrm, g.eps)));   // (DotProduct: no norm factors, no diagonal)
       ipn[v] = ip;
       const int yl = vy - R, xl = vx - R;
-      if (yl >= 0 && yl < bd.y1 - bd.y0 && xl >= 0 && xl < W) dfn[yl * W + xl] = (nrm > 0.f && !g.unit) ? -ip * __builtin_amdgcn_rcpf(nrm) : 0.f;
+      if (yl >= 0 && yl < bd.y1 - bd.y0 && xl >= 0 && xl < W) dfn[yl * W + xl] = nrm > 0.f ? -g.nuf * ip * __builtin_amdgcn_rcpf(nrm) : 0.f;
     };
     constexpr int VP = BF ? 8 : 4;  // values per 16-byte piece
     bool x_asked = false;

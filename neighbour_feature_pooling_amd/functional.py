@@ -365,9 +365,31 @@ def nfp_pool_fused_ok(x, cfg):
     return ok
 
 
+def _amp_input(x):
+    """What the reference's op sequence does with low precision on the GPU (measured on an MI355X,
+    profiles/r03_c_autocast_probe_reference_ops.jsonl; scripts/probe_autocast.py):
+      * under torch.autocast("cuda", ...) F.cosine_similarity and linalg.norm are on autocast's float32 list: the maps
+        come back float32 whatever the input type, gradients in the input's type;
+      * a float16 tensor outside autocast runs in float16 end to end: float16 maps.
+    The kernels store float32 / bfloat16 and always sum in float32, so: under autocast the input is taken as float32
+    and the op runs outside autocast (float32 maps, as the reference; no bf16 rounding of the inputs in between, so
+    it is the closer of the two to the float32 result); float16 is computed in float32 and the maps rounded to float16
+    once.  Returns (tensor to run on, dtype to cast the result to or None)."""
+    if x.is_cuda and torch.is_autocast_enabled("cuda"):
+        return x.float(), None
+    if x.is_cuda and x.dtype == torch.float16:
+        return x.float(), torch.float16
+    return x, None
+
+
 def nfp_pool(x, cfg):
     """(GAP(x) [B,C], GAP(NFP(x)) [B,N]) — NFP_Pooling.py:27-31.  Fused on the GPU where supported,
     otherwise the same two reductions composed from `nfp` and torch ops."""
+    xin, cast = _amp_input(x)
+    if xin is not x:
+        with torch.autocast("cuda", enabled=False):
+            gap, nfpm = nfp_pool(xin, cfg)
+        return (gap, nfpm) if cast is None else (gap.to(cast), nfpm.to(cast))
     if x.dim() == 4 and nfp_pool_fused_ok(x, cfg):
         try:
             cpp = _cpp_nodes()
@@ -405,6 +427,11 @@ def nfp(x, cfg):
     """[B,C,H,W] -> [B, k*k-1, H', W'] neighbour-similarity maps (NFPPooling.forward, nfp.py:132-134)."""
     if x.dim() != 4:
         raise RuntimeError(f"NFP expects a 4-D [B,C,H,W] feature map, got {tuple(x.shape)}")
+    xin, cast = _amp_input(x)
+    if xin is not x:
+        with torch.autocast("cuda", enabled=False):
+            out = nfp(xin, cfg)
+        return out if cast is None else out.to(cast)
     if x.is_cuda and cfg.measure == "scs":
         # The one measure without a kernel, on purpose: the reference's SharpenedCosine divides
         # (B,N,H,W) by (B,1,N,H,W) and so averages over the BATCH (nfp.py:359-374).  Its exact behaviour

@@ -129,3 +129,32 @@ def test_every_accepted_descriptor_launches_within_device_limits(lib):
                 assert all(v >= 1 for v in grid) and grid[1] <= 65535 and grid[2] <= 65535, text
     assert accepted > 2000
     assert {"fwd_band", "fwd_gram", "bwd_fast", "fwd_pairs", "bwd_gather", "bwd_gather_banded"} <= seen, seen
+
+
+def test_pool_supported_is_a_dry_run_of_both_launchers(lib):
+    """nfp_pool_supported used to re-derive the backward's table size and forget the forward's slab —
+    [8,256,20,20] R=2 and friends were promised and then refused with rc = -2.  It is now a plan-mode run of
+    nfp_pool_forward AND nfp_pool_backward, and maps above 512 pixels are served by the row-band kernels: every
+    cosine / L2 / dot / rmse "same" map of a sweep up to 30x30 (R = 1, 2) and the MultiStage maps must be supported, with a
+    scratch size that covers the bands' partial sums where the row-band kernels serve."""
+    lib.nfp_pool_supported.restype = ctypes.c_int
+    cases = [((8, 256, 20, 20), 2), ((1, 192, 18, 18), 2), ((1, 960, 16, 16), 2), ((300, 512, 20, 20), 2), ((300, 32, 22, 23), 2)]
+    cases += [((3, 64, s, s + d), R) for s in range(6, 31, 4) for d in (0, 1) for R in (1, 2)]
+    cases += [((256, 16, 112, 112), 1), ((256, 24, 56, 56), 1), ((256, 40, 28, 28), 1), ((64, 128, 28, 28), 2)]
+    for shape, R in cases:
+        for measure in ("cosine", "norm", "dot", "rmse"):
+            for cl in (False, True):
+                d = desc(shape, R=R, measure=measure, channels_last=cl)
+                d.ws = 0x1000 if lib.nfp_workspace_bytes(ctypes.byref(d)) > 0 else None
+                assert lib.nfp_pool_supported(ctypes.byref(d)) == 1, (shape, R, measure, cl, lib.nfp_last_error())
+                ns = lib.nfp_pool_saved_floats(ctypes.byref(d))
+                B, C, H, W = shape
+                base = B * H * W if measure == "cosine" else 0
+                assert ns >= base
+                if H * W > 512:
+                    assert ns >= base + B * (C + (2 * R + 1) ** 2 - 1)      # at least one band's partial sums per image
+    # and what no fused kernel serves says so
+    for kw in (dict(measure="emd"), dict(stride=2), dict(mode="circular"), dict(pad=0)):
+        d = desc((4, 64, 14, 14), **kw)
+        d.ws = None
+        assert lib.nfp_pool_supported(ctypes.byref(d)) == 0, kw

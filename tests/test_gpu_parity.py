@@ -141,7 +141,7 @@ def test_unbuilt_measure_fails_loudly(dev):
     assert rel_err(out.cpu().numpy(), load_golden("m_scs_p2")["out"]) <= TOL
     n0 = _launches()
     with pytest.raises(_abi.NfpUnsupported, match="float32 or bfloat16"):   # refused before anything is launched
-        NFPPooling(8, padding=1, measure="cosine")(torch.randn(1, 8, 5, 5, device=dev, dtype=torch.float16))
+        NFPPooling(8, padding=1, measure="cosine")(torch.randn(1, 8, 5, 5, device=dev, dtype=torch.float64))
     assert _launches() == n0
     for p in (float("inf"), 0, -2):           # LA.norm orders with other semantics: refused, never mis-computed
         with pytest.raises(_abi.NfpUnsupported, match="norm order"):
@@ -1124,3 +1124,95 @@ def test_cpp_autograd_nodes_equal_python_nodes(dev):
             assert torch.equal(u, v)
     with pytest.raises(_abi.NfpUnsupported, match="norm order"):
         NFPPooling(8, padding=1, measure="norm", p=float("inf"))(torch.randn(1, 8, 5, 5, device=dev))
+
+
+# ---- round 3: parity hardening -------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("name", [c["name"] for c in K.CASES
+                                  if c["ctor"]["measure"].lower() in ("norm", "rmse") and c["ctor"].get("p", 1) in (1, 2)])
+def test_distance_maps_match_the_reference_element_wise(name, dev):
+    """L2 / L1 / RMSE maps have one sign and similar magnitudes, so an element-wise bound means something (VERDICT r2,
+    weak #2): |out - ref| <= 1e-5 |ref| + 1e-6 max|ref| against the real reference's golden output."""
+    c = K.BY_NAME[name]
+    g = load_golden(name)
+    if "out" not in g:
+        pytest.skip("large case: the fixture holds samples and sums only")
+    out, _, _ = run_hip(c, dev)
+    ref = g["out"].astype(np.float64)
+    ok = np.isfinite(ref)
+    assert np.all(np.abs(out.astype(np.float64) - ref)[ok] <= 1e-5 * np.abs(ref[ok]) + 1e-6 * np.abs(ref[ok]).max())
+
+
+@pytest.mark.parametrize("shape,ctor,layout,dtype,fwd,bwd", [
+    ((256, 512, 7, 7), dict(R=1, measure="cosine", padding=1), "nchw", torch.float32, "fwd_band<R1,cos,f32,nchw,pool>", "bwd_fast<R1,cos,f32,nchw,pool>"),
+    ((256, 512, 7, 7), dict(R=1, measure="cosine", padding=1), "nhwc", torch.bfloat16, "fwd_gram<R1,cos,bf16,nhwc,pool>", "bwd_fast<R1,cos,bf16,nhwc,mfma,pool>"),
+    ((256, 192, 14, 14), dict(R=2, measure="norm", p=2, padding=2), "nhwc", torch.bfloat16, "fwd_gram<R2,l2,bf16,nhwc,pool>", "bwd_fast<R2,l2,bf16,nhwc,mfma,pool>"),
+])
+def test_fused_pooling_tail_against_the_oracle_at_config_shapes(shape, ctor, layout, dtype, fwd, bwd, dev, oracle_lib):
+    """The pooled kernels the train steps of configs[3] / configs[4] actually run (fwd_band / fwd_gram <...,pool>,
+    bwd_fast<...[,mfma],pool>) against the CPU ORACLE — not against this package's own nfp + mean composition
+    (VERDICT r2, weak #1): gap, nfpm and grad_x for a loss that weights both pooled outputs."""
+    from neighbour_feature_pooling_amd import NFPPooling, _abi
+    from neighbour_feature_pooling_amd.functional import nfp_pool
+    from neighbour_feature_pooling_amd.synth import feature_map
+    B, C, H, W = shape
+    m = NFPPooling(C, **ctor)
+    N = m.out_channels
+    xh = feature_map(shape, 611)
+    if dtype == torch.bfloat16:
+        xh = K._bf16_round(xh)
+    wg, wn = feature_map((B, C), 612), feature_map((B, N), 613)
+    x = torch.from_numpy(xh).to(dev).to(dtype)
+    if layout == "nhwc":
+        x = x.contiguous(memory_format=torch.channels_last)
+    x.requires_grad_(True)
+    L = _abi.load()
+    gap, nfpm = nfp_pool(x, m.config)
+    fv = L.nfp_last_variant().decode()
+    ((gap * torch.from_numpy(wg).to(dev)).sum() + (nfpm * torch.from_numpy(wn).to(dev)).sum()).backward()
+    torch.cuda.synchronize()
+    bv = L.nfp_last_variant().decode()
+    assert fv.startswith(fwd) and bv.startswith(bwd), (fv, bv)
+    # oracle: the maps, their means, and the gradient of the same loss: grad_out[b,n,p] = wn[b,n] / P, plus wg[b,c] / P
+    P = H * W
+    ref_map = oracle_lib.forward(xh, **ctor)
+    go = np.broadcast_to((wn / P)[:, :, None, None], ref_map.shape).astype(np.float32).copy()
+    ref_gx = oracle_lib.backward(xh, go, **ctor) + (wg / P)[:, :, None, None]
+    bf = dtype == torch.bfloat16
+    assert rel_err(gap.detach().cpu().numpy(), xh.mean((2, 3))) <= (1e-5 if not bf else 1e-5)       # sums of the stored inputs, in f32
+    assert rel_err(nfpm.detach().cpu().numpy(), ref_map.mean((2, 3))) <= (1e-5 if not bf else 1e-2)
+    assert rel_err(x.grad.float().cpu().numpy(), ref_gx) <= (1e-5 if not bf else 2e-2)
+
+
+def test_autocast_and_float16_follow_the_reference_policy(dev):
+    """SURVEY a7 / VERDICT r2 item 7c.  Measured on this GPU with the reference's own op sequence (oracle/unfold_torch.py,
+    profiles/r03_c_autocast_probe_reference_ops.jsonl): under torch.autocast the maps come back float32 (cosine_similarity
+    and linalg.norm are on autocast's float32 list), gradients in the input's type; a float16 tensor outside autocast
+    gives float16 maps.  The op here does the same, computing in float32."""
+    from neighbour_feature_pooling_amd import NFPPooling
+    from oracle.unfold_torch import UnfoldNFP
+    for meas, kw in (("cosine", {}), ("norm", {"p": 2})):
+        ctor = dict(R=1, measure=meas, padding=1, **kw)
+        m = NFPPooling(64, **ctor)
+        ref_m = UnfoldNFP(64, **ctor)
+        ref_m.w_comp, ref_m.w_centre = ref_m.w_comp.to(dev), ref_m.w_centre.to(dev)
+        x32 = torch.randn(2, 64, 7, 7, device=dev)
+        exact = ref_m(x32)
+        for ac in (torch.bfloat16, torch.float16):
+            for xdt in (torch.float32, torch.bfloat16, torch.float16):
+                x = x32.to(xdt).requires_grad_(True)
+                xr = x32.to(xdt).requires_grad_(True)
+                with torch.autocast("cuda", ac):
+                    out, ref = m(x), ref_m(xr)
+                (gx,) = torch.autograd.grad(out.float().sum(), x)
+                (gr,) = torch.autograd.grad(ref.float().sum(), xr)
+                assert out.dtype == ref.dtype == torch.float32 and gx.dtype == gr.dtype == xdt
+                # both are within the reference's own low-precision error of the float32 result
+                assert rel_err(out.detach().cpu().numpy(), exact.cpu().numpy()) <= 1e-2
+        x = x32.half().requires_grad_(True)          # float16 outside autocast
+        xr = x32.half().requires_grad_(True)
+        ref_m.w_comp, ref_m.w_centre = ref_m.w_comp.half(), ref_m.w_centre.half()
+        out, ref = m(x), ref_m(xr)
+        (gx,) = torch.autograd.grad(out.float().sum(), x)
+        assert out.dtype == ref.dtype == torch.float16 and gx.dtype == torch.float16
+        assert rel_err(out.detach().float().cpu().numpy(), exact.cpu().numpy()) <= 2e-3
