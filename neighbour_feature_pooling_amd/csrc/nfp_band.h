@@ -251,7 +251,7 @@ __global__ void __launch_bounds__(1024) fwd_band(const KP g, const void* __restr
         const float n2q = n2[q - p0];
         float v;
         if (M == NFP_COSINE) {
-          const float s = kind == 2 ? 0.f : (kind == 1 ? n2p : pairv) * ip * unit_or(g, inv_norm(n2q, g.inv_eps));
+          const float s = kind == 2 ? 0.f : prod_value(g, kind == 1 ? n2p : pairv, n2p, n2q, ip, unit_or(g, inv_norm(n2q, g.inv_eps)));
           v = fin_prod(g, s);
         } else {
           float d2;

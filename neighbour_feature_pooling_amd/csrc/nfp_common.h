@@ -44,10 +44,30 @@ struct KP {
   //                                         subgradient at distance 0 (zero0 = 0: torch's sqrt gives inf * 0 = NaN there)
   float osa, osb, d2s;
   int unit, zero0;
+  int gfc;         // GFC on the product kernels (below)
+  float gf, ngf;   // (float)gfc and 1 - (float)gfc
   float uf, nuf;   // (float)unit and 1 - (float)unit: "1 if unit else v" as fmaf(v, nuf, uf) — exact, and not a branch on a
                    // wave-uniform flag in the latency-critical finalize
 };
 __device__ __forceinline__ float unit_or(const KP& g, float v) { return fmaf(v, g.nuf, g.uf); }
+// GFC (nfp.py:265-276): num / (|a| |b| + eps).  Its gradient has the shape of cosine's — per pair {g', g' f}, a cross
+// weight and a pull on |x| — with other post-factors, so it rides on the product kernels too (round 3).  With the
+// per-pixel factor F (cosine: 1 / max(|x|, eps); dot: 1; gfc: |x| itself):
+//   cross weight of a pair (r, t)          cosine / dot: F_r F_t          gfc: 1 / (F_r F_t + eps)
+//   what a pair adds to r's diagonal sum   cosine / dot: 1                gfc: F_t / (F_r F_t + eps)
+// (then times dfn[r]: cosine -1 / (|x| max(|x|, eps)), dot 0, gfc -1 / |x|).  Blended by fmaf on gf = (float)gfc, not
+// selected: a select on a wave-uniform flag is a branch.
+__device__ __forceinline__ float cross_f(const KP& g, float fr, float ft) {
+  return fmaf(__builtin_amdgcn_rcpf(fmaf(fr, ft, g.eps)), g.gf, fr * ft * g.ngf);
+}
+__device__ __forceinline__ float diag_f(const KP& g, float fr, float ft) {
+  return fmaf(ft * __builtin_amdgcn_rcpf(fmaf(fr, ft, g.eps)), g.gf, g.ngf);
+}
+// forward: pair sum -> s.  cosine / dot: pair * ip * iq; gfc: pair / (sqrt(n2p) sqrt(n2q) + eps)
+__device__ __forceinline__ float prod_value(const KP& g, float pairv, float n2p, float n2q, float ip, float iq) {
+  const float gq = __builtin_amdgcn_rcpf(fmaf(__builtin_amdgcn_sqrtf(n2p), __builtin_amdgcn_sqrtf(n2q), g.eps));
+  return pairv * fmaf(gq, g.gf, ip * iq * g.ngf);
+}
 __device__ __forceinline__ float fin_prod(const KP& g, float s) { return fmaf(g.osa, s, g.osb); }
 __device__ __forceinline__ float fin_dist(const KP& g, float d2) { return g.osa * __builtin_amdgcn_sqrtf(d2 * g.d2s); }
 // per-pair backward scalar of a distance map: d out / d (a - b)[c] = coefficient * (a - b)[c]

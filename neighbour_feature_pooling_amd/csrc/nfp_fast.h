@@ -644,8 +644,8 @@ __global__ void __launch_bounds__(GEMM ? 1024 : kBwdThreads) bwd_fast(const KP g
   }
   if (M == NFP_COSINE && t < P) {
     const float ip = unit_or(g, __builtin_amdgcn_rcpf(fmaxf(nrm, g.eps)));   // (DotProduct: no norm factors, no diagonal)
-    ipn[t] = ip;
-    dfn[t] = nrm > 0.f ? -g.nuf * ip * __builtin_amdgcn_rcpf(nrm) : 0.f;
+    ipn[t] = fmaf(nrm, g.gf, ip * g.ngf);                                     // (GFC: the norm itself — nfp_common.h::cross_f)
+    dfn[t] = nrm > 0.f ? -fmaf(1.f, g.gf, g.nuf * ip * g.ngf) * __builtin_amdgcn_rcpf(nrm) : 0.f;
   }
   if constexpr (SYM) {  // slots before the centre whose pixel lies outside the image keep this 0 (Wt and Dt are adjacent)
     for (int i = t; i < (2 * P * K2) >> 2; i += T) ((float4*)Wt)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -708,12 +708,13 @@ __global__ void __launch_bounds__(GEMM ? 1024 : kBwdThreads) bwd_fast(const KP g
         take(r1.w >> 16);
       }
       const int tt = tqc == 0xFFFFu ? r : (int)tqc;
-      wv = M == NFP_COSINE ? ipn[r] * ipn[tt] * S : (g.diff ? -S : 0.f);
+      wv = M == NFP_COSINE ? cross_f(g, ipn[r], ipn[tt]) * S : (g.diff ? -S : 0.f);
       if (SYM && tqc != 0xFFFFu) {  // the same pairs, seen from t
         const int em = tt * K2 + (K2 - 1 - j);
         Wt[em] = wv;
-        Dt[em] = M == NFP_COSINE ? Dj : Dm;
+        Dt[em] = M == NFP_COSINE ? Dj * diag_f(g, ipn[tt], ipn[r]) : Dm;
       }
+      if (M == NFP_COSINE) Dj *= diag_f(g, ipn[r], ipn[tt]);
     } else {
       // centre slot: its row carries the pixel's two tap masks instead of links (zero-padded taps, self pairs)
       uint32_t zm = r0.x, sm = r0.y;
@@ -725,7 +726,8 @@ __global__ void __launch_bounds__(GEMM ? 1024 : kBwdThreads) bwd_fast(const KP g
           S += 2.f * v.x;
           Dj += 2.f * v.y;
         }
-        wv = ipn[r] * ipn[r] * S;
+        wv = cross_f(g, ipn[r], ipn[r]) * S;
+        Dj *= diag_f(g, ipn[r], ipn[r]);
       } else {
         uint32_t m = g.diff ? zm : sm;  // diff: |x_p - 0| still pulls on x_p; quirk: |x_q| with q == p
         while (m) {

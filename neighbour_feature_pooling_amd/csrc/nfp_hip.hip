@@ -69,7 +69,10 @@ int make_kp(const nfp_desc* d, KP* g) {
   g->invPT = 1.0f / (float)((g->P & 3) > 0 ? (g->P & 3) : 1);
   g->inv_eps = 1.0f / g->eps;
   // run-time constants of the hot-path kernels (nfp_common.h): products out = osa * s + osb, distances out = osa * sqrt(d2 * d2s)
-  const bool prod = d->measure == NFP_COSINE || d->measure == NFP_DOT;
+  const bool prod = d->measure == NFP_COSINE || d->measure == NFP_DOT || d->measure == NFP_GFC;
+  g->gfc = d->measure == NFP_GFC ? 1 : 0;
+  g->gf = (float)g->gfc;
+  g->ngf = 1.0f - g->gf;
   g->unit = d->measure == NFP_DOT ? 1 : 0;
   g->uf = (float)g->unit;
   g->nuf = 1.0f - g->uf;
@@ -482,7 +485,7 @@ template <int R, int M>
 int launch_fwd_gram(const KP& g, const void* x, void* out, float* saved, hipStream_t st, float* gap = nullptr,
                     float* nfpm = nullptr) {
   if (!mfma_enabled() || g.dtype != NFP_BF16 || (g.C & 15) || g.P > 512) return kNotApplicable;
-  if (g.unit || g.d2s != 1.f) return kNotApplicable;   // (DotProduct / RMSE: the vector kernels' run-time constants)
+  if (g.unit || g.gfc || g.d2s != 1.f) return kNotApplicable;   // (DotProduct / GFC / RMSE: the vector kernels' run-time constants)
   if (!g.contig && (((uintptr_t)x & 15) || ((g.sB * 2) & 15))) return kNotApplicable;  // 16-byte fragment loads
   const int nt = (g.P + 31) / 32, D = std::min(nt - 1, (g.R * g.W + g.R + 31) / 32);
   const size_t tiles = (((size_t)nt * (D + 1) * 32 * kGramLd + 3) & ~(size_t)3) * 4;

@@ -137,13 +137,13 @@ int launch(const char* name, K kernel, dim3 grid, dim3 block, size_t lds, hipStr
 }
 
 // The hot-path kernels (nfp_band.h / nfp_fast.h / nfp_mfma.h / nfp_tile.h) are instantiated for the product form (Cosine) and
-// the squared-difference form (L2); DotProduct and RMSE ride on them through KP's run-time constants (nfp_common.h).
-inline bool hot_product(const KP& g) { return g.measure == NFP_COSINE || g.measure == NFP_DOT; }
+// the squared-difference form (L2); DotProduct, GFC and RMSE ride on them through KP's run-time constants (nfp_common.h).
+inline bool hot_product(const KP& g) { return g.measure == NFP_COSINE || g.measure == NFP_DOT || g.measure == NFP_GFC; }
 inline bool hot_measure(const KP& g) {
   return hot_product(g) || (g.measure == NFP_NORM && g.p == 2.f) || g.measure == NFP_RMSE;
 }
 inline const char* hot_name(const KP& g) {
-  return g.measure == NFP_COSINE ? "cos" : (g.measure == NFP_DOT ? "dot" : (g.measure == NFP_RMSE ? "rmse" : "l2"));
+  return g.measure == NFP_COSINE ? "cos" : (g.measure == NFP_DOT ? "dot" : (g.measure == NFP_GFC ? "gfc" : (g.measure == NFP_RMSE ? "rmse" : "l2")));
 }
 inline bool force_generic() { return g_sw.force_generic.load(std::memory_order_relaxed) != 0; }
 inline int round4(int v) { return (v + 3) & ~3; }

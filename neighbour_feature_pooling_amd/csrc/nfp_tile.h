@@ -319,7 +319,7 @@ __global__ void __launch_bounds__(1024, (R == 1 ? 8 : 4)) fwd_tile(const KP g, c
       const float n2q = n2[qv];
       float val;
       if (M == NFP_COSINE) {
-        const float s = pairv * ip * unit_or(g, inv_norm(n2q, g.inv_eps));
+        const float s = prod_value(g, pairv, n2p, n2q, ip, unit_or(g, inv_norm(n2q, g.inv_eps)));
         val = fin_prod(g, s);
       } else {
         val = fin_dist(g, g.diff ? pairv : n2q);  // 'Norm' quirk (nfp.py:74 vs 85): |neighbour|
@@ -440,9 +440,10 @@ __global__ void __launch_bounds__(512) bwd_tile(const KP g, const TileGeo tg, co
       const int sy = fo.y(bd.y0 - R + vy, H), sx = fo.x(vx - R, W);
       const float nrm = (sy | sx) < 0 ? 0.f : nrm_raw;
       const float ip = unit_or(g, __builtin_amdgcn_rcpf(fmaxf(nrm, g.eps)));   // (DotProduct: no norm factors, no diagonal)
-      ipn[v] = ip;
+      ipn[v] = fmaf(nrm, g.gf, ip * g.ngf);                                     // (GFC: the norm itself — nfp_common.h::cross_f)
       const int yl = vy - R, xl = vx - R;
-      if (yl >= 0 && yl < bd.y1 - bd.y0 && xl >= 0 && xl < W) dfn[yl * W + xl] = nrm > 0.f ? -g.nuf * ip * __builtin_amdgcn_rcpf(nrm) : 0.f;
+      if (yl >= 0 && yl < bd.y1 - bd.y0 && xl >= 0 && xl < W)
+        dfn[yl * W + xl] = nrm > 0.f ? -fmaf(1.f, g.gf, g.nuf * ip * g.ngf) * __builtin_amdgcn_rcpf(nrm) : 0.f;
     };
     constexpr int VP = BF ? 8 : 4;  // values per 16-byte piece
     bool x_asked = false;
@@ -586,8 +587,8 @@ __global__ void __launch_bounds__(512) bwd_tile(const KP g, const TileGeo tg, co
           const bool ok = jv[n] >= 0;
           float add;
           if (M == NFP_COSINE) {
-            add = ok ? ipr * iq[n] * qv[n].x : 0.f;
-            Dsum += ok ? qv[n].y : 0.f;
+            add = ok ? cross_f(g, ipr, iq[n]) * qv[n].x : 0.f;
+            Dsum += ok ? qv[n].y * diag_f(g, ipr, iq[n]) : 0.f;
           } else {
             add = ok ? dneg * qv[n].x : 0.f;
             Dsum += ok ? qv[n].x : 0.f;
@@ -621,8 +622,8 @@ __global__ void __launch_bounds__(512) bwd_tile(const KP g, const TileGeo tg, co
       const int j = n < K2 / 2 ? n : n + 1;
       if (M == NFP_COSINE) {
         const float S = v1[n].x + (inb[n] ? v2[n].x : 0.f);
-        Dsum += v1[n].y + (inb[n] ? v2[n].y : 0.f);
-        wrow[j] = fmaf(ipr * ipq[n], S, wl[j]);
+        Dsum += (v1[n].y + (inb[n] ? v2[n].y : 0.f)) * diag_f(g, ipr, ipq[n]);
+        wrow[j] = fmaf(cross_f(g, ipr, ipq[n]), S, wl[j]);
       } else {
         const float c1 = v1[n].x, c2 = inb[n] ? v2[n].x : 0.f;
         wrow[j] = fmaf(dneg, c1 + c2, wl[j]);
