@@ -57,7 +57,10 @@ struct FoffQ {
 // Thread maps.  Channel sums: thread t = lp * G + gl — the G channel groups of a pixel are ADJACENT LANES (G a power
 // of two <= 32, g.G; g.Tc = log2 G), so the groups' partial sums are joined by a fixed DPP tree inside the wavefront:
 // no LDS round trip, no barrier.  Outputs: thread t = gl' * Ps + lp' — lanes along pixels, coalesced stores.
-template <int R, int M, bool BF, bool NHWC, bool POOL = false>
+// VAR: one of the measures that ride on these kernels through KP's run-time constants (DotProduct, GFC, RMSE:
+// nfp_common.h).  Cosine and L2 themselves keep the finalize of round 2, constants folded: the three extra transcendental
+// instructions of the general form sit on the critical path of a 5 us kernel (4.97 vs 4.87 us at the headline shape).
+template <int R, int M, bool BF, bool NHWC, bool POOL = false, bool VAR = false>
 __global__ void __launch_bounds__(1024) fwd_band(const KP g, const void* __restrict__ x, void* __restrict__ out,
                                                  float* __restrict__ saved, const unsigned char* __restrict__ ws,
                                                  int rb, float* __restrict__ gap, float* __restrict__ nfpm) {
@@ -241,7 +244,7 @@ __global__ void __launch_bounds__(1024) fwd_band(const KP g, const void* __restr
   if (glf < Gn) {
     void* ob = (char*)out + (long long)b * N * P * ES;
     const float n2p = n2[lpf];
-    const float ip = unit_or(g, inv_norm(n2p, g.inv_eps));
+    const float ip = VAR ? unit_or(g, inv_norm(n2p, g.inv_eps)) : inv_norm(n2p, g.inv_eps);
     for (int n = glf; n < N; n += Gn) {
       const uint32_t e = n == glf ? fte : ftt[n * P + pf];
       const int kind = (int)(e >> 22), pix = (int)((e >> 9) & 511u), fi = (int)((e >> 18) & 15u);
@@ -251,15 +254,25 @@ __global__ void __launch_bounds__(1024) fwd_band(const KP g, const void* __restr
         const float n2q = n2[q - p0];
         float v;
         if (M == NFP_COSINE) {
-          const float s = kind == 2 ? 0.f : prod_value(g, kind == 1 ? n2p : pairv, n2p, n2q, ip, unit_or(g, inv_norm(n2q, g.inv_eps)));
-          v = fin_prod(g, s);
+          if constexpr (VAR) {
+            const float s = kind == 2 ? 0.f : prod_value(g, kind == 1 ? n2p : pairv, n2p, n2q, ip, unit_or(g, inv_norm(n2q, g.inv_eps)));
+            v = fin_prod(g, s);
+          } else {
+            const float s = kind == 2 ? 0.f : (kind == 1 ? n2p : pairv) * ip * inv_norm(n2q, g.inv_eps);
+            v = g.similarity ? s : 1.f - s;
+          }
         } else {
           float d2;
           if (g.diff)
             d2 = kind == 2 ? n2p : (kind == 1 ? 0.f : pairv);
           else
             d2 = kind == 2 ? 0.f : n2q;  // 'Norm' quirk (nfp.py:74 vs 85): |neighbour|
-          v = fin_dist(g, d2);
+          if constexpr (VAR) {
+            v = fin_dist(g, d2);
+          } else {
+            const float dd = __builtin_amdgcn_sqrtf(d2);
+            v = g.similarity ? -dd : dd;
+          }
         }
         stx(ob, n * P + pf, v, BF ? NFP_BF16 : NFP_F32);
         if constexpr (POOL) Tt[NV + n * Ps + lpf] = v;  // vm[n][p], behind the half-stencil table

@@ -418,7 +418,10 @@ int launch_fwd_band_t(KP g, const void* x, void* out, float* saved, hipStream_t 
            BF ? "bf16" : "f32", NHWC ? "nhwc" : "nchw", POOL ? ",pool" : "", nb);
   if (nb_out) *nb_out = nb;
   // (pooled, several bands: the bands' partial sums go to `part`; the caller folds them — pool_forward_rm)
-  return launch("fwd_band", fwd_band<R, M, BF, NHWC, POOL>, dim3(g.B, nb), dim3(T), lds, st, g, x, out, saved, g.ws,
+  if (g.unit || g.gfc || g.d2s != 1.f)   // DotProduct / GFC / RMSE: the finalize with the run-time constants
+    return launch("fwd_band", fwd_band<R, M, BF, NHWC, POOL, true>, dim3(g.B, nb), dim3(T), lds, st, g, x, out, saved, g.ws,
+                  rb, (POOL && nb > 1) ? part : gap, nfpm);
+  return launch("fwd_band", fwd_band<R, M, BF, NHWC, POOL, false>, dim3(g.B, nb), dim3(T), lds, st, g, x, out, saved, g.ws,
                 rb, (POOL && nb > 1) ? part : gap, nfpm);
 }
 

@@ -19,3 +19,14 @@ timeout -k 10 400 python bench.py --steps 20 --warmup 5 > gpurun_out/r03_bench_2
 timeout -k 10 400 python bench.py > gpurun_out/r03_bench_200.json 2>> gpurun_out/r03_bench.err; echo "bench200 rc=$?"
 NFP_BENCH_BACKEND=gloo timeout -k 10 300 python bench.py --gpus 2 --no-cpu-baseline --steps 20 --warmup 5 > gpurun_out/r03_bench_gpus2_gloo.json 2> gpurun_out/r03_bench_gpus2.err; echo "bench --gpus 2 (gloo, self-launched) rc=$?"
 cut -c1-400 gpurun_out/r03_bench_200.json; cut -c1-300 gpurun_out/r03_bench_gpus2_gloo.json
+# round-2 kernels (commit bee0a3b, built into neighbour_feature_pooling_amd/ab/ by hand) beside this round's, same box,
+# alternating processes: the headline, the per-GPU batch of config 4, the saturating batch
+if [ -f neighbour_feature_pooling_amd/ab/manifest.json ]; then
+  for shp in 64,512,7,1,cosine 256,512,7,1,cosine 4096,512,7,1,cosine; do
+    echo "== $shp"; AB_COLD=1 AB_SHAPE=$shp timeout -k 10 300 python scripts/ab_flags.py --run 2>&1 | grep "fwd" | cut -c1-170
+  done > gpurun_out/r03_ab_round2_vs_round3.txt
+  cat gpurun_out/r03_ab_round2_vs_round3.txt
+fi
+timeout -k 10 200 python scripts/sweep_bigmaps.py gpurun_out/r03_bigmaps_final.jsonl > gpurun_out/r03_bigmaps_final.log 2>&1; echo "bigmaps sweep rc=$?"
+timeout -k 10 200 python scripts/sweep.py > gpurun_out/r03_shape_sweep.jsonl 2>&1; echo "shape sweep rc=$?"
+timeout -k 10 200 python scripts/gpu_fused_callers.py > gpurun_out/r03_fused_callers.jsonl 2>&1; echo "fused callers rc=$?"
