@@ -211,12 +211,17 @@ __global__ void __launch_bounds__(1024) fwd_band(const KP g, const void* __restr
       for (int cq = gl; cq < ncq; cq += G) {
         const float4* row = slab + cq * Ppb + sp;
         const float4 a = row[0];
-        nrm = fmaf(a.x, a.x, fmaf(a.y, a.y, fmaf(a.z, a.z, fmaf(a.w, a.w, nrm))));
+        if (M == kNormP1)   // (Norm p = 1, nfp.py:141-148 with the class default p: sums of |.|; |x_p|_1 for the 'Norm' quirk)
+          nrm += (fabsf(a.x) + fabsf(a.y)) + (fabsf(a.z) + fabsf(a.w));
+        else
+          nrm = fmaf(a.x, a.x, fmaf(a.y, a.y, fmaf(a.z, a.z, fmaf(a.w, a.w, nrm))));
 #pragma unroll
         for (int d = 0; d < NF; ++d) {
           const float4 q = row[off[d]];
           if (M == NFP_COSINE) {
             acc[d] = fmaf(a.x, q.x, fmaf(a.y, q.y, fmaf(a.z, q.z, fmaf(a.w, q.w, acc[d]))));
+          } else if (M == kNormP1) {
+            acc[d] += (fabsf(a.x - q.x) + fabsf(a.y - q.y)) + (fabsf(a.z - q.z) + fabsf(a.w - q.w));
           } else {
             const float e0 = a.x - q.x, e1 = a.y - q.y, e2 = a.z - q.z, e3 = a.w - q.w;
             acc[d] = fmaf(e0, e0, fmaf(e1, e1, fmaf(e2, e2, fmaf(e3, e3, acc[d]))));
@@ -267,7 +272,9 @@ __global__ void __launch_bounds__(1024) fwd_band(const KP g, const void* __restr
             d2 = kind == 2 ? n2p : (kind == 1 ? 0.f : pairv);
           else
             d2 = kind == 2 ? 0.f : n2q;  // 'Norm' quirk (nfp.py:74 vs 85): |neighbour|
-          if constexpr (VAR) {
+          if constexpr (M == kNormP1) {
+            v = g.similarity ? -d2 : d2;   // (no root: the sum of |.| is the norm)
+          } else if constexpr (VAR) {
             v = fin_dist(g, d2);
           } else {
             const float dd = __builtin_amdgcn_sqrtf(d2);

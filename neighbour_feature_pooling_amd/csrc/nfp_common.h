@@ -136,6 +136,8 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ float sgnf(float v) { return (float)((v > 0.f) - (v < 0.f)); }
+// the same in three instructions (compare, select, bit-field insert of the sign) for the channel loops of Norm p = 1
+__device__ __forceinline__ float sgn3(float v) { return __builtin_copysignf(v != 0.f ? 1.f : 0.f, v); }
 
 // Per-channel arithmetic of the measures (term / grad, evaluated C*N times per output pixel): hardware
 // reciprocal and square root (1 ulp) instead of the ~10-instruction IEEE sequences.  x/0, 0/0 and inf/inf

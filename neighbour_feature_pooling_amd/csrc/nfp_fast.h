@@ -624,7 +624,7 @@ __global__ void __launch_bounds__(GEMM ? 1024 : kBwdThreads) bwd_fast(const KP g
         const float sg = g.osa * gc;
         AD[o + k] = make_float2(sg, sg * s);
       } else {
-        CC[o + k] = dist_coef(g, gc, oc);
+        CC[o + k] = M == kNormP1 ? g.osa * gc : dist_coef(g, gc, oc);   // (p = 1: d out / d (a - b)[c] = +-g sign(a - b)[c])
       }
     }
   };
@@ -680,8 +680,11 @@ __global__ void __launch_bounds__(GEMM ? 1024 : kBwdThreads) bwd_fast(const KP g
         } else {
           const float cv = CC[o];
           S += on ? cv : 0.f;
-          Dj += (on && (g.diff || (ent & 0x8000u))) ? cv : 0.f;   // 'Norm' quirk: only the pair's NEIGHBOUR is pulled
-          Dm += (on && (g.diff || !(ent & 0x8000u))) ? cv : 0.f;  // (bit 15: r is the neighbour of this pair)
+          // 'Norm' quirk: only the pair's NEIGHBOUR is pulled (bit 15: r is the neighbour of this pair).  p = 1 with the
+          // difference weights has no diagonal at all: the pull on x_r sits inside sign(x_r - x_t)
+          const bool dall = M == kNormP1 ? false : (bool)g.diff;
+          Dj += (on && (dall || (!g.diff && (ent & 0x8000u)))) ? cv : 0.f;
+          Dm += (on && (dall || (!g.diff && !(ent & 0x8000u)))) ? cv : 0.f;
         }
       };
       auto live = [&](uint32_t w2) { return __ballot((w2 & 0xFFFFu) != 0xFFFFu) != 0; };  // wave-uniform
@@ -708,7 +711,7 @@ __global__ void __launch_bounds__(GEMM ? 1024 : kBwdThreads) bwd_fast(const KP g
         take(r1.w >> 16);
       }
       const int tt = tqc == 0xFFFFu ? r : (int)tqc;
-      wv = M == NFP_COSINE ? cross_f(g, ipn[r], ipn[tt]) * S : (g.diff ? -S : 0.f);
+      wv = M == NFP_COSINE ? cross_f(g, ipn[r], ipn[tt]) * S : (g.diff ? (M == kNormP1 ? S : -S) : 0.f);
       if (SYM && tqc != 0xFFFFu) {  // the same pairs, seen from t
         const int em = tt * K2 + (K2 - 1 - j);
         Wt[em] = wv;
@@ -833,13 +836,28 @@ __global__ void __launch_bounds__(GEMM ? 1024 : kBwdThreads) bwd_fast(const KP g
           const float4 gg = *(const float4*)(ggap + (long long)b * g.C + c0 + 4 * cq);
           r4 = make_float4(gg.x * g.invP, gg.y * g.invP, gg.z * g.invP, gg.w * g.invP);
         }
+        if constexpr (M == kNormP1) {
+          // Norm p = 1: grad_x[c][r] = sum_t W[r][t] sign(x_r - x_t)[c]  (+ the centre weight times sign(x_r): zero-padded
+          // taps with the difference weights, neighbour roles with the 'Norm' quirk)
+          const float4 a = row[0];
 #pragma unroll
-        for (int j = 0; j < K2; ++j) {
-          const float4 q = row[off[j]];
-          r4.x = fmaf(w[j], q.x, r4.x);
-          r4.y = fmaf(w[j], q.y, r4.y);
-          r4.z = fmaf(w[j], q.z, r4.z);
-          r4.w = fmaf(w[j], q.w, r4.w);
+          for (int j = 0; j < K2; ++j) {
+            const float4 q = row[off[j]];
+            const bool c = j == K2 / 2;
+            r4.x = fmaf(w[j], sgn3(c ? a.x : a.x - q.x), r4.x);
+            r4.y = fmaf(w[j], sgn3(c ? a.y : a.y - q.y), r4.y);
+            r4.z = fmaf(w[j], sgn3(c ? a.z : a.z - q.z), r4.z);
+            r4.w = fmaf(w[j], sgn3(c ? a.w : a.w - q.w), r4.w);
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < K2; ++j) {
+            const float4 q = row[off[j]];
+            r4.x = fmaf(w[j], q.x, r4.x);
+            r4.y = fmaf(w[j], q.y, r4.y);
+            r4.z = fmaf(w[j], q.z, r4.z);
+            r4.w = fmaf(w[j], q.w, r4.w);
+          }
         }
         if constexpr (NHWC) {
           store_px4<BF>(gxb, p * g.C + c0 + 4 * cq, 0, r4);

@@ -339,7 +339,7 @@ bool fast_geometry(const KP& g) {
 bool fast_ok(const KP& g, const void* x, const void* gx) {
   if (force_generic()) return false;
   if (!fast_geometry(g) || (g.C & 3)) return false;
-  if (!hot_measure(g)) return false;
+  if (!hot_measure(g) && !hot_l1(g)) return false;
   const bool nhwc = g.sC == 1 && g.sW == g.C && g.sH == (long long)g.W * g.C;
   if (!g.contig && !nhwc) return false;
   if (!g.contig) {  // vector loads of 4 channels need natural alignment
@@ -643,7 +643,7 @@ int forward_impl(const nfp_desc* d, const void* x, void* out, float* saved, void
   if (g.B == 0) return NFP_OK;
   hipStream_t st = (hipStream_t)hip_stream;
   if (g.rs == 12) {
-    if (g.ws == nullptr || !fast_ok(g, x, x))
+    if (g.ws == nullptr || !fast_ok(g, x, x) || hot_l1(g))
       return fail(NFP_E_UNSUPPORTED, "multi-radius: cosine / L2 on maps of at most %d pixels, C %% 4 == 0, dense layout, "
                   "descriptor with a workspace", kBwdThreads);
     const int rc = hot_product(g) ? launch_fwd_band<12, NFP_COSINE>(g, x, out, saved, st)
@@ -652,7 +652,10 @@ int forward_impl(const nfp_desc* d, const void* x, void* out, float* saved, void
   }
   if (g_sw.tile_first.load(std::memory_order_relaxed))
     if (int rc = tile_forward(g, x, out, saved, st, false, nullptr, nullptr); rc != kNotApplicable) return rc;
-  if (fast_ok(g, x, x)) {
+  if (fast_ok(g, x, x) && hot_l1(g)) {
+    const int rc = g.R == 1 ? launch_fwd_band<1, kNormP1>(g, x, out, saved, st) : launch_fwd_band<2, kNormP1>(g, x, out, saved, st);
+    if (rc != kNotApplicable) return rc;
+  } else if (fast_ok(g, x, x)) {
     int rc;
     if (hot_product(g))
       rc = g.R == 1 ? launch_fwd_gram<1, NFP_COSINE>(g, x, out, saved, st)
@@ -719,7 +722,7 @@ int backward_impl(const nfp_desc* d, const void* x, const void* grad_out, const 
   if (g.B == 0) return NFP_OK;
   hipStream_t st = (hipStream_t)hip_stream;
   if (g.rs == 12) {
-    if (g.ws == nullptr || !fast_ok(g, x, grad_x))
+    if (g.ws == nullptr || !fast_ok(g, x, grad_x) || hot_l1(g))
       return fail(NFP_E_UNSUPPORTED, "multi-radius: cosine / L2 on maps of at most %d pixels, C %% 4 == 0, dense layout, "
                   "descriptor with a workspace", kBwdThreads);
     const int rc = hot_product(g) ? launch_bwd_vec<12, NFP_COSINE>(g, x, grad_out, out, saved, grad_x, st)
@@ -728,7 +731,11 @@ int backward_impl(const nfp_desc* d, const void* x, const void* grad_out, const 
   }
   if (g_sw.tile_first.load(std::memory_order_relaxed))
     if (int rc = tile_backward(g, x, grad_out, out, saved, grad_x, st, false, nullptr, nullptr); rc != kNotApplicable) return rc;
-  if (g.ws != nullptr && fast_ok(g, x, grad_x)) {
+  if (g.ws != nullptr && fast_ok(g, x, grad_x) && hot_l1(g)) {
+    const int rc = g.R == 1 ? launch_bwd_vec<1, kNormP1>(g, x, grad_out, out, saved, grad_x, st)
+                            : launch_bwd_vec<2, kNormP1>(g, x, grad_out, out, saved, grad_x, st);
+    if (rc != kNotApplicable) return rc;
+  } else if (g.ws != nullptr && fast_ok(g, x, grad_x)) {
     int rc;
     if (hot_product(g))
       rc = g.R == 1 ? launch_bwd_fast<1, NFP_COSINE>(g, x, grad_out, out, saved, grad_x, st)

@@ -142,7 +142,11 @@ inline bool hot_product(const KP& g) { return g.measure == NFP_COSINE || g.measu
 inline bool hot_measure(const KP& g) {
   return hot_product(g) || (g.measure == NFP_NORM && g.p == 2.f) || g.measure == NFP_RMSE;
 }
+// Norm p = 1 (the class default, nfp.py:16): instantiations of its own of the table kernels (sums of |a - b|; a gradient
+// in sign(a - b)), plain maps only — no fused pooling tail, no multi-radius, no row-band kernels yet.
+inline bool hot_l1(const KP& g) { return g.measure == NFP_NORM && g.p == 1.f; }
 inline const char* hot_name(const KP& g) {
+  if (hot_l1(g)) return "l1";
   return g.measure == NFP_COSINE ? "cos" : (g.measure == NFP_DOT ? "dot" : (g.measure == NFP_GFC ? "gfc" : (g.measure == NFP_RMSE ? "rmse" : "l2")));
 }
 inline bool force_generic() { return g_sw.force_generic.load(std::memory_order_relaxed) != 0; }

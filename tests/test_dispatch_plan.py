@@ -70,12 +70,16 @@ def test_plan_does_not_launch_or_disturb_last_variant(lib):
      "fwd_gram<R2,l2,bf16,nhwc>", "bwd_fast<R2,l2,bf16,nhwc,mfma>"),                                    # 256 x 13 = 3328 entries
     (dict(shape=(4, 64, 18, 18), R=2, measure="norm", dtype=_abi.BF16, channels_last=True),
      "fwd_gram<R2,l2,bf16,nhwc>", "bwd_fast<R2,l2,bf16,nhwc>"),                                         # 324 x 13 = 4212: vector kernel
-    (dict(shape=(64, 512, 7, 7), measure="norm", p=1.0), "fwd_pairs", "bwd_gather"),                    # reference default p
+    (dict(shape=(64, 512, 7, 7), measure="norm", p=1.0), "fwd_band<R1,l1,f32,nchw>x4", "bwd_fast<R1,l1,f32,nchw>"),   # reference default p: table kernels since round 3
+    (dict(shape=(64, 512, 7, 7), measure="norm", p=3.0), "fwd_pairs", "bwd_gather"),                    # any other order
     (dict(shape=(64, 512, 7, 7), pad=0), "fwd_pairs", "bwd_gather"),                                    # pad != R
     (dict(shape=(64, 512, 7, 7), stride=2), "fwd_pairs", "bwd_gather"),
     (dict(shape=(64, 510, 7, 7)), "fwd_pairs", "bwd_gather"),                                           # C % 4 != 0
     (dict(shape=(4, 64, 7, 7), mode="circular"), "fwd_pairs", "bwd_gather"),
     (dict(shape=(4, 64, 7, 7), measure="jeffrey"), "fwd_pairs", "bwd_gather"),
+    (dict(shape=(64, 512, 7, 7), measure="dot"), "fwd_band<R1,dot,f32,nchw>x4", "bwd_fast<R1,dot,f32,nchw>"),   # round 3: on the product kernels
+    (dict(shape=(64, 512, 7, 7), measure="gfc"), "fwd_band<R1,gfc,f32,nchw>x4", "bwd_fast<R1,gfc,f32,nchw>"),
+    (dict(shape=(64, 512, 7, 7), measure="rmse"), "fwd_band<R1,rmse,f32,nchw>x4", "bwd_fast<R1,rmse,f32,nchw>"),  # ... and the L2 kernels
     (dict(shape=(4, 64, 7, 7), measure="attention"), "fwd_pairs+attn_softmax", "bwd_gather"),
     (dict(shape=(64, 64, 56, 56)), "fwd_tile<R1,cos,f32,nchw>x8", "bwd_tile<R1,cos,f32,nchw>x8"),     # > 512 px: row bands
     (dict(shape=(256, 16, 112, 112)), "fwd_tile<R1,cos,f32,nchw>x19", "bwd_tile<R1,cos,f32,nchw>x28"),
