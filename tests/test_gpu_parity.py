@@ -1216,3 +1216,92 @@ def test_autocast_and_float16_follow_the_reference_policy(dev):
         (gx,) = torch.autograd.grad(out.float().sum(), x)
         assert out.dtype == ref.dtype == torch.float16 and gx.dtype == torch.float16
         assert rel_err(out.detach().float().cpu().numpy(), exact.cpu().numpy()) <= 2e-3
+
+
+# ---- cases the suite did not reach -----------------------------------------------------------------
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(8, 8, 9, 3), (28, 8, 9, 3), (5, 16, 11, 3), (3, 8, 13, 5)])
+def test_band_forward_overlapped_last_block_below_the_band_origin(shape, dtype, dev, monkeypatch):
+    """H*W % 4 != 0 with a last band that starts on an 8-aligned pixel above P - 4: the NCHW staging's overlapped last
+    block begins below the band's slot origin (fwd_band's commit redirects those three slots).  Against the float64
+    formulation, forward and backward."""
+    from neighbour_feature_pooling_amd import NFPPooling, _abi
+    from neighbour_feature_pooling_amd._host import nfp_host
+    from neighbour_feature_pooling_amd.synth import feature_map
+    nfp_switch(monkeypatch, "NFP_MFMA", "0")         # (bf16 with C % 16 == 0 would take the matrix-core forward)
+    m = NFPPooling(shape[1], R=1, measure="cosine", padding=1)
+    x = torch.from_numpy(feature_map(shape, 77)).to(dev).to(dtype).requires_grad_(True)
+    out = m(x)
+    assert _abi.load().nfp_last_variant().decode().startswith("fwd_band<R1,cos")
+    go = torch.from_numpy(feature_map(tuple(out.shape), 78)).to(dev).to(dtype)
+    gx, = torch.autograd.grad(out, x, go)
+    x64 = x.detach().double().requires_grad_(True)
+    ref = nfp_host(x64, m.config)
+    gref, = torch.autograd.grad(ref, x64, go.double())
+    to, tg = (TOL, TOL) if dtype == torch.float32 else (1e-2, 2e-2)
+    assert rel_err(out.detach().float().cpu().numpy(), ref.detach().cpu().numpy()) <= to
+    assert rel_err(gx.float().cpu().numpy(), gref.cpu().numpy()) <= tg
+
+
+@pytest.mark.parametrize("shape", [(3, 32, 16, 16), (2, 64, 20, 20), (2, 32, 22, 23), (9, 256, 20, 20)])
+@pytest.mark.parametrize("measure", ["cosine", "norm"])
+def test_fused_callers_between_196_and_512_pixels(shape, measure, dev):
+    """The fused pooling tail and the multi-radius maps with R = 2 above 14x14 (where round 2's nfp_pool_supported promised
+    descriptors its launchers then refused, and where the multi-radius backward does not fit and training falls back to two
+    passes while no_grad uses the fused kernel): each against the composition of the plain ops, forward and backward,
+    and the no_grad result against the training-mode one."""
+    from neighbour_feature_pooling_amd import MultiRadiusNFPPooling, NFPPooling
+    from neighbour_feature_pooling_amd.functional import nfp, nfp_pool
+    from neighbour_feature_pooling_amd.synth import feature_map
+    B, C, H, W = shape
+    ctor = dict(R=2, measure=measure, padding=2, **({"p": 2} if measure == "norm" else {}))
+    m = NFPPooling(C, **ctor)
+    x1 = torch.from_numpy(feature_map(shape, 31)).to(dev).requires_grad_(True)
+    x2 = x1.detach().clone().requires_grad_(True)
+    gap, nfpm = nfp_pool(x1, m.config)
+    rg, rn = x2.mean((2, 3)), nfp(x2, m.config).mean((2, 3))
+    assert rel_err(gap.detach().cpu().numpy(), rg.detach().cpu().numpy()) <= 2e-6
+    assert rel_err(nfpm.detach().cpu().numpy(), rn.detach().cpu().numpy()) <= 2e-6
+    wg = torch.from_numpy(feature_map((B, C), 32)).to(dev)
+    wn = torch.from_numpy(feature_map((B, 24), 33)).to(dev)
+    ((gap * wg).sum() + (nfpm * wn).sum()).backward()
+    ((rg * wg).sum() + (rn * wn).sum()).backward()
+    assert rel_err(x1.grad.cpu().numpy(), x2.grad.cpu().numpy()) <= TOL
+    # multi-radius (1, 2): training mode (fused or two passes, whichever the backward allows) vs no_grad (fused forward)
+    mr = MultiRadiusNFPPooling(C, R_list=(1, 2), measure=measure, **({"p": 2} if measure == "norm" else {}))
+    x3 = x1.detach().clone().requires_grad_(True)
+    y = mr(x3)
+    with torch.no_grad():
+        y0 = mr(x1.detach())
+    ref = torch.cat([blk(x1.detach()) for blk in mr.nfp_blocks], dim=1)
+    assert rel_err(y.detach().cpu().numpy(), ref.cpu().numpy()) <= 2e-6
+    assert rel_err(y0.cpu().numpy(), ref.cpu().numpy()) <= 2e-6
+    go = torch.from_numpy(feature_map(tuple(y.shape), 34)).to(dev)
+    (g3,) = torch.autograd.grad(y, x3, go)
+    x4 = x1.detach().clone().requires_grad_(True)
+    (g4,) = torch.autograd.grad(torch.cat([blk(x4) for blk in mr.nfp_blocks], dim=1), x4, go)
+    assert rel_err(g3.cpu().numpy(), g4.cpu().numpy()) <= TOL
+
+
+def test_workspace_first_seen_inside_a_graph_capture(dev):
+    """a geometry first seen under capture used to get its table fill RECORDED, not run, and the unfilled
+    buffer cached.  Now that call runs without tables (general kernels, a RuntimeWarning) and nothing is cached: the
+    replay and later eager calls agree with an eager reference."""
+    from neighbour_feature_pooling_amd import NFPPooling, functional
+    m = NFPPooling(8, R=1, measure="cosine", padding=1)
+    x = torch.randn(2, 8, 6, 5, device=dev)          # a geometry no other test uses
+    key = [k for k in functional._WORKSPACES if k[1:3] == (6, 5)]
+    assert not key
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        g = torch.cuda.CUDAGraph()
+        with pytest.warns(RuntimeWarning, match="graph capture"):
+            with torch.cuda.graph(g, stream=s):
+                y = m(x)
+        g.replay()
+    torch.cuda.synchronize()
+    assert not [k for k in functional._WORKSPACES if k[1:3] == (6, 5)]
+    y2 = m(x)                                          # eager: builds the tables now
+    assert [k for k in functional._WORKSPACES if k[1:3] == (6, 5)]
+    assert rel_err(y.cpu().numpy(), y2.cpu().numpy()) <= 2e-6
