@@ -367,7 +367,9 @@ __global__ void __launch_bounds__(256) pool_fold(const float* __restrict__ part,
 
 // ---- backward -----------------------------------------------------------------------------------------------------------
 // POOL: grad_out is not a map: go[b,n,p] = gnfpm[b,n] / P for every p, and every grad_x[b,c,p] also gets ggap[b,c] / P.
-template <int R, int M, bool BF, bool NHWC, bool POOL = false>
+// GFC: the general post-factors of nfp_common.h::cross_f / diag_f (a reciprocal per window slot); cosine and dot keep the
+// plain product of the two per-pixel factors.
+template <int R, int M, bool BF, bool NHWC, bool POOL = false, bool GFC = false>
 __global__ void __launch_bounds__(512) bwd_tile(const KP g, const TileGeo tg, const void* __restrict__ x,
                                                 const void* __restrict__ go, const void* __restrict__ out,
                                                 const float* __restrict__ saved, void* __restrict__ gx,
@@ -384,11 +386,12 @@ __global__ void __launch_bounds__(512) bwd_tile(const KP g, const TileGeo tg, co
   const int W = g.W, H = g.H, P = g.P, Wp = bd.Wp, Wu = bd.Wu, npu = bd.npu, nbp = bd.nbp;
   const int ya = max(0, bd.y0 - R), yb = min(H, bd.y1 + R), npA = (yb - ya) * W;  // rows whose pairs touch the band
   const int cb0 = cblk * g.Cwg, cb1 = min(g.C, cb0 + g.Cwg);
-  // LDS: Wt [nbp][K2] | ipn [npu] | dfn [nbp] | pair values [N][npA] — and the x slab over the pair values
-  float* Wt = (float*)lds4;
-  float* ipn = Wt + nbp * K2;
+  // LDS: ipn [npu] | dfn [nbp] | pair values [N][npA] — and the x slab over the pair values.  (The window weights never
+  // go through LDS: the thread that builds a pixel's row in phase A is the thread that uses it in phase B; with several
+  // channel groups per pixel every group builds the row for itself.)
+  float* ipn = (float*)lds4;
   float* dfn = ipn + npu;
-  float4* pv4 = lds4 + ((nbp * K2 + npu + nbp + 3) >> 2);
+  float4* pv4 = lds4 + ((npu + nbp + 3) >> 2);
   float2* AD = (float2*)pv4;  // cosine: {sg, sg * s}
   float* CC = (float*)pv4;    // L2: c = -+g / d
   float4* slab = pv4;
@@ -440,10 +443,10 @@ __global__ void __launch_bounds__(512) bwd_tile(const KP g, const TileGeo tg, co
       const int sy = fo.y(bd.y0 - R + vy, H), sx = fo.x(vx - R, W);
       const float nrm = (sy | sx) < 0 ? 0.f : nrm_raw;
       const float ip = unit_or(g, __builtin_amdgcn_rcpf(fmaxf(nrm, g.eps)));   // (DotProduct: no norm factors, no diagonal)
-      ipn[v] = fmaf(nrm, g.gf, ip * g.ngf);                                     // (GFC: the norm itself — nfp_common.h::cross_f)
+      ipn[v] = GFC ? nrm : ip;                                                  // (GFC: the norm itself — nfp_common.h::cross_f)
       const int yl = vy - R, xl = vx - R;
       if (yl >= 0 && yl < bd.y1 - bd.y0 && xl >= 0 && xl < W)
-        dfn[yl * W + xl] = nrm > 0.f ? -fmaf(1.f, g.gf, g.nuf * ip * g.ngf) * __builtin_amdgcn_rcpf(nrm) : 0.f;
+        dfn[yl * W + xl] = nrm > 0.f ? -(GFC ? 1.f : g.nuf * ip) * __builtin_amdgcn_rcpf(nrm) : 0.f;
     };
     constexpr int VP = BF ? 8 : 4;  // values per 16-byte piece
     bool x_asked = false;
@@ -527,13 +530,19 @@ __global__ void __launch_bounds__(512) bwd_tile(const KP g, const TileGeo tg, co
   NFP_STAMP(2);
 
   const float dneg = g.diff ? -1.f : 0.f;   // L2: cross weight = -c with the difference weights, 0 with the 'Norm' quirk
-  // ---- A2: window weights of every band pixel, by the pixel's own thread (fixed order, one writer per row) ------------
-  for (int lp = t; lp < nbp; lp += T) {
-    const int yl = fdivi(lp, W), xx = lp - yl * W, y = bd.y0 + yl;
+  // ---- A2: the window weights of this thread's pixel, in registers (fixed order; bitwise reproducible) -----------------
+  const int gl = fdivi(t, nbp), lp = t - gl * nbp;
+  const bool active = gl < g.G;
+  const int yl = fdivi(lp, W), xx = lp - yl * W, y = bd.y0 + yl;
+  const int pos = (yl + R) * Wp + kXL + xx, sp = swz(pos);
+  const int p = y * W + xx;
+  float w[K2];
+  auto crossw = [&](float fr, float ft) { return GFC ? cross_f(g, fr, ft) : fr * ft; };
+  auto diagw = [&](float fr, float ft) { return GFC ? diag_f(g, fr, ft) : 1.f; };
+  if (active) {
     const int pv = (yl + R) * Wu + xx + R, lpA = (y - ya) * W + xx;
     const float ipr = M == NFP_COSINE ? ipn[pv] : 1.f;
     float Dsum = 0.f;
-    float* wrow = Wt + lp * K2;
     // Pixels within R of the image border also collect the pairs whose neighbour is a RING position that folds onto them
     // (reflect / replicate).  By the pixel's own thread: a wavefront with a border pixel pays one trip of the loop below
     // per valid ring position (an edge pixel has one, a corner three) while the other wavefronts do the same for theirs;
@@ -587,8 +596,8 @@ __global__ void __launch_bounds__(512) bwd_tile(const KP g, const TileGeo tg, co
           const bool ok = jv[n] >= 0;
           float add;
           if (M == NFP_COSINE) {
-            add = ok ? cross_f(g, ipr, iq[n]) * qv[n].x : 0.f;
-            Dsum += ok ? qv[n].y * diag_f(g, ipr, iq[n]) : 0.f;
+            add = ok ? crossw(ipr, iq[n]) * qv[n].x : 0.f;
+            Dsum += ok ? qv[n].y * diagw(ipr, iq[n]) : 0.f;
           } else {
             add = ok ? dneg * qv[n].x : 0.f;
             Dsum += ok ? qv[n].x : 0.f;
@@ -598,14 +607,20 @@ __global__ void __launch_bounds__(512) bwd_tile(const KP g, const TileGeo tg, co
         }
       }
     }
-    // every LDS read of the pixel first (one batch: the writes below could alias them for all the compiler knows)
+    // every LDS read of the pixel first, then the sums
     float2 v1[N], v2[N];
     float ipq[N];
     bool inb[N];
+    bool iny[K], inx[K];
+#pragma unroll
+    for (int d = 0; d < K; ++d) {
+      iny[d] = y + d - R >= 0 && y + d - R < H;
+      inx[d] = xx + d - R >= 0 && xx + d - R < W;
+    }
 #pragma unroll
     for (int n = 0; n < N; ++n) {
       const int j = n < K2 / 2 ? n : n + 1, dy = j / K - R, dx = j % K - R, opp = N - 1 - n;
-      inb[n] = y + dy >= 0 && y + dy < H && xx + dx >= 0 && xx + dx < W;
+      inb[n] = iny[dy + R] && inx[dx + R];
       const int i1 = n * npA + lpA, i2 = inb[n] ? opp * npA + lpA + dy * W + dx : i1;
       if (M == NFP_COSINE) {
         v1[n] = AD[i1];
@@ -622,32 +637,27 @@ __global__ void __launch_bounds__(512) bwd_tile(const KP g, const TileGeo tg, co
       const int j = n < K2 / 2 ? n : n + 1;
       if (M == NFP_COSINE) {
         const float S = v1[n].x + (inb[n] ? v2[n].x : 0.f);
-        Dsum += (v1[n].y + (inb[n] ? v2[n].y : 0.f)) * diag_f(g, ipr, ipq[n]);
-        wrow[j] = fmaf(cross_f(g, ipr, ipq[n]), S, wl[j]);
+        Dsum += (v1[n].y + (inb[n] ? v2[n].y : 0.f)) * diagw(ipr, ipq[n]);
+        w[j] = fmaf(crossw(ipr, ipq[n]), S, wl[j]);
       } else {
         const float c1 = v1[n].x, c2 = inb[n] ? v2[n].x : 0.f;
-        wrow[j] = fmaf(dneg, c1 + c2, wl[j]);
+        w[j] = fmaf(dneg, c1 + c2, wl[j]);
         Dsum += fmaf(-dneg, c1, c2);  // 'Norm' quirk (nfp.py:74 vs 85): only the pair's NEIGHBOUR is pulled
       }
     }
-    wrow[K2 / 2] = fmaf(M == NFP_COSINE ? dfn[lp] : 1.f, Dsum, wl[K2 / 2]);
+    w[K2 / 2] = fmaf(M == NFP_COSINE ? dfn[lp] : 1.f, Dsum, wl[K2 / 2]);
+  } else {
+#pragma unroll
+    for (int j = 0; j < K2; ++j) w[j] = 0.f;
   }
   NFP_STAMP(9);
-  __syncthreads();  // weights complete; the pair values are dead: their LDS becomes the x slab
+  __syncthreads();  // the pair values are dead: their LDS becomes the x slab
   NFP_STAMP(3);
 
   // ---- B: one pass over the channel block ---------------------------------------------------------------------------
-  const int gl = fdivi(t, nbp), lp = t - gl * nbp;
-  const bool active = gl < g.G;
-  const int yl = fdivi(lp, W), xl = lp - yl * W, pos = (yl + R) * Wp + kXL + xl, sp = swz(pos);
-  const int p = (bd.y0 + yl) * W + xl;
-  float w[K2];
   int off[K2];
 #pragma unroll
-  for (int j = 0; j < K2; ++j) {
-    off[j] = swz(pos + (j / K - R) * Wp + (j % K - R)) - sp;
-    w[j] = active ? Wt[lp * K2 + j] : 0.f;
-  }
+  for (int j = 0; j < K2; ++j) off[j] = swz(pos + (j / K - R) * Wp + (j % K - R)) - sp;
   for (int c0 = cb0; c0 < cb1; c0 += g.Cc) {
     const int ncq = min(g.Cc, cb1 - c0) >> 2;
     if (c0 > cb0) __syncthreads();  // previous chunk fully consumed

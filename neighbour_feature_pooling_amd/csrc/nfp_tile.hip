@@ -88,7 +88,7 @@ int launch_fwd_tile_t(KP g, const void* x, void* out, float* saved, hipStream_t 
 template <int R, int M, bool BF, bool NHWC, bool POOL = false>
 int launch_bwd_tile_t(KP g, const void* x, const void* go, const void* out, const float* saved, void* gx, hipStream_t st,
                       const float* ggap = nullptr, const float* gnfpm = nullptr) {
-  constexpr int N = Win<R>::N, K2 = Win<R>::K2;
+  constexpr int N = Win<R>::N;
   const int Wp = nfp::tile_row_stride(g.W, R), Wu = g.W + 2 * R, pvw = M == NFP_COSINE ? 2 : 1;
   const int rb_max = std::min(g.H, 512 / g.W);
   if (rb_max < 1) return kNotApplicable;
@@ -99,7 +99,7 @@ int launch_bwd_tile_t(KP g, const void* x, const void* go, const void* out, cons
       const int rb = ceil_div(g.H, nb);
       nb = ceil_div(g.H, rb);
       const int rows = rb + 2 * R, npos = rows * Wp, npu = rows * Wu, nbp = rb * g.W, npA = std::min(g.H, rows) * g.W;
-      const size_t fixed = ((size_t)(nbp * K2 + npu + nbp) * 4 + 15) & ~(size_t)15;
+      const size_t fixed = ((size_t)(npu + nbp) * 4 + 15) & ~(size_t)15;   // ipn, dfn (the window weights live in registers)
       const size_t pv = (size_t)N * npA * pvw * 4;
       const int ppb = npos | 1;
       if (fixed + std::max(pv, (size_t)ppb * 16) > budget) continue;
@@ -126,6 +126,11 @@ int launch_bwd_tile_t(KP g, const void* x, const void* go, const void* out, cons
       nfp::TileGeo tg = {rb, nb, Wp, S};
       snprintf(g_variant, sizeof(g_variant), "bwd_tile<R%d,%s,%s,%s%s>x%d", R, hot_name(g), BF ? "bf16" : "f32",
                NHWC ? "nhwc" : "nchw", POOL ? ",pool" : "", nb);
+      if constexpr (M == NFP_COSINE) {
+        if (g.gfc)
+          return launch("bwd_tile", bwd_tile<R, M, BF, NHWC, POOL, true>, dim3((unsigned)(g.B * nb * S)), dim3(T), lds, st, g, tg, x, go,
+                        out, saved, gx, ggap, gnfpm);
+      }
       return launch("bwd_tile", bwd_tile<R, M, BF, NHWC, POOL>, dim3((unsigned)(g.B * nb * S)), dim3(T), lds, st, g, tg, x, go, out,
                     saved, gx, ggap, gnfpm);
     }
