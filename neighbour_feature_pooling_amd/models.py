@@ -161,6 +161,19 @@ class MobileNetV3LargeFeatures(nn.Module):
 
     forward = forward_features
 
+    # timm's `features_only=True` taps of mobilenetv3_large_100 (what MobileNetV3_MultiStageNFP reads,
+    # texture_pooling.py:222-226): the last layer at each stride — 16 ch @ /2, 24 @ /4, 40 @ /8, 112 @ /16, 960 @ /32
+    STAGE_ENDS = (3, 5, 8, 14, 20)          # indices into self.features (stem = 0..2, then the 15 blocks, then the 1x1 head)
+    STAGE_CHANNELS = (16, 24, 40, 112, 960)
+
+    def forward_stages(self, x):
+        feats = []
+        for i, layer in enumerate(self.features):
+            x = layer(x)
+            if i in self.STAGE_ENDS:
+                feats.append(x)
+        return feats
+
 
 BACKBONES = {"resnet18": ResNet18Features, "vit_tiny_patch16_224": ViTTinyFeatures,
              "mobilenetv3_large_100": MobileNetV3LargeFeatures}
@@ -190,3 +203,28 @@ class NFPNet(nn.Module):
             feats = tok.transpose(1, 2).unflatten(2, (H, W))
         x = self.pool(feats)
         return self.fc(x.view(x.size(0), -1))
+
+
+class MultiStageNFPNet(nn.Module):
+    """texture_pooling.py::MobileNetV3_MultiStageNFP (211-268) with the local backbone: NFP(cosine, R = 1, padding = 1) on all
+    five stage outputs (112x112x16 ... 7x7x960 at 224x224), each averaged to 8 values (249-252), the 40 values projected to
+    the head width and multiplied into GAP(conv_head(last map)).  The per-stage `F.adaptive_avg_pool2d(NFP(feat), 1)` is the
+    pooled half of the fused tail (functional.nfp_pool): on the GPU the maps above 512 pixels run on the row-band kernels
+    of csrc/nfp_tile.h, the small ones on the table kernels."""
+
+    def __init__(self, num_classes=10, num_input_channels=3, head_width=1280):
+        super().__init__()
+        from .nfp import NFPPooling
+        self.backbone = MobileNetV3LargeFeatures(in_chans=num_input_channels)
+        self.nfps = nn.ModuleList(NFPPooling(in_channels=c, R=1, measure="cosine", padding=1)
+                                  for c in MobileNetV3LargeFeatures.STAGE_CHANNELS)
+        self.conv_head = nn.Sequential(nn.Conv2d(960, head_width, 1), nn.Hardswish(inplace=True))   # timm: conv_head + act2
+        self.nfp_proj = nn.Linear(8 * len(self.nfps), head_width)
+        self.fc = nn.Linear(head_width, num_classes)
+
+    def forward(self, x):
+        from .functional import nfp_pool
+        feats = self.backbone.forward_stages(x)
+        v = torch.cat([nfp_pool(f, layer.config)[1].to(f.dtype) for f, layer in zip(feats, self.nfps)], dim=1)   # [B, 40]
+        head = self.conv_head(feats[-1]).mean((2, 3))
+        return self.fc(head * self.nfp_proj(v))

@@ -20,11 +20,13 @@ import torch.distributed as dist
 import torch.nn as nn
 from torch.nn.parallel import DistributedDataParallel as DDP
 
-from .models import NFPNet
+from .models import MultiStageNFPNet, NFPNet
 from .nfp import NFPPooling
 
 
 def build(model="resnet18", num_classes=10, in_chans=3, image=224, nfp=None, device="cpu", dtype=torch.float32):
+    if model == "mobilenetv3_multistage":      # texture_pooling.py:211-268: NFP on all five stage outputs
+        return MultiStageNFPNet(num_classes=num_classes, num_input_channels=in_chans).to(device=device, dtype=dtype)
     kw = {"img_size": image} if model.startswith("vit") else {}
     net = NFPNet(model, num_classes=num_classes, num_input_channels=in_chans, nfp_layer=nfp, **kw)
     return net.to(device=device, dtype=dtype)
@@ -54,7 +56,7 @@ def synthetic_batch(batch, in_chans, image, num_classes, device, dtype, seed):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--model", default="resnet18", choices=["resnet18", "vit_tiny_patch16_224", "mobilenetv3_large_100"])
+    ap.add_argument("--model", default="resnet18", choices=["resnet18", "vit_tiny_patch16_224", "mobilenetv3_large_100", "mobilenetv3_multistage"])
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch")
     ap.add_argument("--image", type=int, default=224)
     ap.add_argument("--in-chans", type=int, default=3)
@@ -95,7 +97,7 @@ def main():
         dist.init_process_group(backend)
     dtype = torch.float32 if a.dtype == "f32" else torch.bfloat16
     torch.manual_seed(0)  # identical initial weights on every rank (DDP also broadcasts rank 0's)
-    C = {"resnet18": 512, "vit_tiny_patch16_224": 192, "mobilenetv3_large_100": 960}[a.model]
+    C = {"resnet18": 512, "vit_tiny_patch16_224": 192, "mobilenetv3_large_100": 960, "mobilenetv3_multistage": 960}[a.model]
     ctor = dict(R=a.nfp_radius, measure=a.nfp_measure, padding=a.nfp_radius)
     if a.nfp_measure == "norm":
         ctor["p"] = 2

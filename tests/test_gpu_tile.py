@@ -140,3 +140,56 @@ def test_fused_pooling_tail_on_large_maps(B, C, H, W, R, meas, layout, dtype):
     assert rel_err(gap.detach().cpu().numpy(), rg.detach().cpu().numpy()) <= tol_o
     assert rel_err(nfpm.detach().cpu().numpy(), rn.detach().cpu().numpy()) <= tol_o
     assert rel_err(gx.float().cpu().numpy(), gref.cpu().numpy()) <= tol_g
+
+
+def test_multistage_network_train_step_runs_on_the_large_map_kernels():
+    """models.MultiStageNFPNet (texture_pooling.py:211-268) at 224x224: the three maps above 512 pixels are served by the
+    pooled row-band kernels (fwd_tile<...,pool> + pool_fold, bwd_tile<...,pool>), the two small ones by the table kernels;
+    the step's loss and the input gradient agree with the same network on the any-geometry kernels."""
+    from neighbour_feature_pooling_amd import _abi
+    from neighbour_feature_pooling_amd.models import MultiStageNFPNet
+    dev = torch.device("cuda:0")
+    L = _abi.load()
+    torch.manual_seed(0)
+    net = MultiStageNFPNet(num_classes=10).to(dev)
+    x = torch.randn(4, 3, 224, 224, device=dev, requires_grad=True)
+    seen = []
+    import neighbour_feature_pooling_amd.functional as Fn
+    orig = Fn.nfp_pool
+
+    def spy(t, cfg):
+        r = orig(t, cfg)
+        seen.append((tuple(t.shape[1:]), L.nfp_last_variant().decode()))
+        return r
+    Fn.nfp_pool = spy
+    try:
+        import neighbour_feature_pooling_amd.models as M
+        n0 = L.nfp_launch_count()
+        loss = net(x).square().mean()
+        loss.backward()
+        torch.cuda.synchronize()
+        n1 = L.nfp_launch_count()
+    finally:
+        Fn.nfp_pool = orig
+    by_shape = dict(seen)
+    for shp in ((16, 112, 112), (24, 56, 56), (40, 28, 28)):
+        assert by_shape[shp].startswith("fwd_tile<R1,cos,f32,nchw,pool>") and by_shape[shp].endswith("+pool_fold"), by_shape
+    for shp in ((112, 14, 14), (960, 7, 7)):
+        assert by_shape[shp].startswith("fwd_band<R1,cos,f32,nchw,pool>"), by_shape
+    assert n1 - n0 == 5 + 3 + 5          # five pooled forwards, three folds, five pooled backwards
+    g1, l1 = x.grad.clone(), loss.item()
+    # the same step on the any-geometry kernels (composition: x.mean + nfp + mean)
+    import os
+    os.environ["NFP_FORCE_GENERIC"] = "1"
+    L.nfp_reload_env()
+    try:
+        x.grad = None
+        net.zero_grad()
+        loss2 = net(x).square().mean()
+        loss2.backward()
+        torch.cuda.synchronize()
+    finally:
+        del os.environ["NFP_FORCE_GENERIC"]
+        L.nfp_reload_env()
+    assert abs(loss2.item() - l1) <= 1e-5 * max(abs(l1), 1e-6) + 1e-7
+    assert rel_err(x.grad.cpu().numpy(), g1.cpu().numpy()) <= 1e-3      # through 20 layers of a random-init trunk

@@ -27,6 +27,24 @@ def test_backbone_output_shapes_and_sizes():
     assert 2.9e6 < n(MobileNetV3LargeFeatures()) < 3.1e6      # 2.97 M  (mobilenetv3_large_100 trunk)
 
 
+def test_multistage_net_mirrors_the_reference_model():
+    """texture_pooling.py::MobileNetV3_MultiStageNFP (211-268): five stage outputs with 16 / 24 / 40 / 112 / 960 channels at
+    strides 2 ... 32 (timm's features_only taps), one NFP(cosine, R = 1, padding = 1) each, 5 x 8 pooled values -> Linear(40,
+    1280), times GAP(conv_head(last map)), classifier."""
+    from neighbour_feature_pooling_amd.models import MultiStageNFPNet
+    with torch.no_grad():
+        feats = MobileNetV3LargeFeatures(3).forward_stages(torch.randn(1, 3, 224, 224))
+    assert [tuple(f.shape[1:]) for f in feats] == [(16, 112, 112), (24, 56, 56), (40, 28, 28), (112, 14, 14), (960, 7, 7)]
+    net = MultiStageNFPNet(num_classes=7)
+    assert [l.in_channels for l in net.nfps] == [16, 24, 40, 112, 960] and all(l.out_channels == 8 for l in net.nfps)
+    assert (net.nfp_proj.in_features, net.nfp_proj.out_features, net.fc.in_features) == (40, 1280, 1280)
+    assert not [n for n, p in net.named_parameters() if "nfps." in n and p.requires_grad]   # NFP has no trainable weights
+    step, _ = make_step(net)
+    x, y = synthetic_batch(2, 3, 64, 7, "cpu", torch.float32, 5)
+    l0 = step(x, y)
+    assert torch.isfinite(l0)
+
+
 @pytest.mark.parametrize("name,image,nfp", [
     ("resnet18", 64, None),
     ("vit_tiny_patch16_224", 64, dict(R=2, measure="norm", p=2, padding=2)),  # config 5 geometry: k=5 L2
