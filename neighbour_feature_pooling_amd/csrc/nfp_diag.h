@@ -9,7 +9,7 @@ __device__ unsigned long long* nfp_stamp_buf = nullptr;
 #define NFP_STAMP_INIT() unsigned long long* nfp_sb_ = nfp_stamp_buf
 #define NFP_STAMP(id)                                                                        \
   do {                                                                                       \
-    if (threadIdx.x == 0 && nfp_sb_) {                                                       \
+    if ((threadIdx.x | threadIdx.y | threadIdx.z) == 0 && nfp_sb_) {                                                       \
       unsigned long long wg = blockIdx.x + (unsigned long long)gridDim.x * blockIdx.y;       \
       nfp_sb_[(wg * 16 + (id)) * 2] = __builtin_amdgcn_s_memtime();                         \
       nfp_sb_[(wg * 16 + (id)) * 2 + 1] = __builtin_amdgcn_s_memrealtime();                 \

@@ -40,6 +40,7 @@ inline void publish_variant() {
 // calls nfp_reload_env): the launch path itself never reads it.
 struct Switches {
   std::atomic<int> fwd_scalar{0}, bwd_atomic{0}, bwd_bands{0}, force_generic{0}, mfma{1}, tile_first{0};
+  std::atomic<int> tile_wgs{0}, tile_lds_kb{0}, tile_cap{0};   // A/B overrides of the row-band launchers' constants (0: built-in)
 };
 inline Switches g_sw;
 #ifndef NFP_MFMA_DEFAULT
@@ -55,8 +56,14 @@ inline void read_env() {
   g_sw.force_generic = flag("NFP_FORCE_GENERIC", 0);
   g_sw.mfma = flag("NFP_MFMA", NFP_MFMA_DEFAULT);
   g_sw.tile_first = flag("NFP_TILE_FIRST", 0);   // A/B: the row-band kernels of nfp_tile.h also for maps the table kernels serve
-  const char* e = getenv("NFP_BWD_BANDS");
-  g_sw.bwd_bands = e ? atoi(e) : 0;
+  auto num = [](const char* name) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : 0;
+  };
+  g_sw.bwd_bands = num("NFP_BWD_BANDS");
+  g_sw.tile_wgs = num("NFP_TILE_WGS");
+  g_sw.tile_lds_kb = num("NFP_TILE_LDS_KB");
+  g_sw.tile_cap = num("NFP_TILE_CAP");
 }
 
 inline int fail(int code, const char* fmt, ...) {
@@ -112,14 +119,15 @@ inline thread_local char t_plan[512] = "";
 
 template <typename K, typename... A>
 int launch(const char* name, K kernel, dim3 grid, dim3 block, size_t lds, hipStream_t st, A... args) {
-  if (lds > (size_t)kLdsMax || block.x < 1 || block.x > 1024 || grid.x < 1 || grid.y < 1 || grid.z < 1 ||
+  const unsigned threads = block.x * block.y * block.z;   // (the row-band kernels launch (groups, columns, rows) blocks)
+  if (lds > (size_t)kLdsMax || threads < 1 || threads > 1024 || grid.x < 1 || grid.y < 1 || grid.z < 1 ||
       grid.y > 65535 || grid.z > 65535)
     return fail(NFP_E_UNSUPPORTED, "%s: launch shape grid (%u,%u,%u) block %u lds %zu outside the device limits", name,
-                grid.x, grid.y, grid.z, block.x, lds);
+                grid.x, grid.y, grid.z, threads, lds);
   if (t_dry) {
     const size_t n = strlen(t_plan);
     snprintf(t_plan + n, sizeof(t_plan) - n, "%s%s grid=(%u,%u,%u) block=%u lds=%zu", n ? "; " : "", name, grid.x, grid.y,
-             grid.z, block.x, lds);
+             grid.z, threads, lds);
     return NFP_OK;
   }
   if (int rc = set_lds(kernel, lds)) return rc;

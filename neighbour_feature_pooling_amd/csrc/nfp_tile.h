@@ -7,75 +7,71 @@
 // nfp_fast.h (nfp.py:141-159: cosine and L2 over "same" maps: stride 1, dilation 1, padding = R), different index
 // scheme: the workspace tables of the small-map kernels grow with H*W and a 7x7 map is half border, a 112x112 map 3 %.
 //
-// A workgroup owns a BAND of rows [y0, y1) of one image.  It stages rows y0-R .. y1+R-1 of a channel chunk into LDS
-// as the PADDED map the reference's F.pad would build (nfp.py:42-58: reflect / replicate / zeros): R ring columns left
-// and right of every row, ring rows above / below the image, every ring slot filled from its fold source while
-// staging.  In padded coordinates every tap of every pixel sits at a CONSTANT offset: the channel loops have no
-// border cases, no index tables, and a zero-padded tap is a zero vector like any other.
+// A workgroup owns a BAND of rows [y0, y1) of one image and works on the PADDED band the reference's F.pad would build
+// (nfp.py:42-58: reflect / replicate / zeros): rows y0-R .. y1+R-1, R ring columns left and right of every row, ring
+// rows above / below the image.  ONE THREAD PER PADDED POSITION (times G channel groups): the workgroup is a
+// (G, W + 2R, rows) block, so a thread's padded column and row are its hardware ids — no division anywhere — and the
+// same thread stages its position (from the position's fold source: a ring position is a second copy of an image
+// pixel), sums it, and writes its outputs.  In padded coordinates every tap of every position sits at a CONSTANT
+// offset: no border cases, no index tables, and a zero-padded tap is a zero vector like any other.
 //   forward   half stencil over padded positions (a pair {u, u+d} is summed once, by the thread of u, ring positions
-//             included), then every output (n, p) of the band's rows looks its pair up; nothing is combined across
-//             workgroups; an output element has one writer.
+//             included), then the thread of a band pixel looks its N pairs up; nothing is combined across workgroups;
+//             an output element has one writer.
 //   backward  gather form as in nfp_fast.h: per band pixel r the window weights W[r][j] (phase A), then
-//             grad_x[c][r] = sum_j W[r][j] * xpad[c][r + d_j] in one pass over the slab (phase B).  Phase A needs no
-//             tables either: slot j of an interior pixel links two pairs (r's tap j; the tap -j of the pixel under
-//             it), and a pixel near the border also collects the pairs whose neighbour is a RING position that folds
-//             onto it — enumerated by the pixel's own thread in a fixed order (no atomics, bitwise reproducible).
+//             grad_x[c][r] = sum_j W[r][j] * xpad[c][r + d_j] in one pass over the slab (phase B).  Phase A is the same
+//             code for every position: a position's slot j links its own pair of tap j and the pair of the opposite
+//             tap of the position under it; positions that own no pairs (ring, outside the image) hold zeros.  A ring
+//             position u is a copy of the image pixel r it folds onto: what its window collects belongs to r, and r's
+//             thread fetches it — shifted by r - u — in a fixed order (no atomics, bitwise reproducible).
 // The halo rows two bands share are re-read from L2: workgroup ids are mapped so that the bands of one image run on ONE
 // XCD (ids are dealt round-robin over the 8 XCDs, each with its own L2).
+//
+// Why this shape (profiles/r03_u_tile_kernels_pmc_before_rewrite.csv): the first cut of these kernels (flat thread ids,
+// 4-pixel staging blocks, swizzled slots) was bound by VALU issue — 446 (forward) / 1306 (backward) vector instructions
+// per wavefront at [256,16,112,112], two thirds of all issue cycles, against ~150 / ~330 that the arithmetic needs: the
+// rest was index arithmetic (divisions by the row length, folds, swizzles, per-tap border predicates).
 #pragma once
+#include <type_traits>
+
 #include "nfp_band.h"
 
 namespace nfp {
 
-// staging registers per thread and chunk: KB 4-pixel x 4-channel blocks (NCHW), KR ring slots (NCHW), KN slots (channels-last).
-// Forward: one block per thread already fills the slab (T threads x 64 bytes = the 60 KB a workgroup may use), and the
-// kernel must stay within 64 registers.  Backward: half as many threads per staged pixel.
-constexpr int kFwdKB = 1, kFwdKR = 1, kFwdKN = 4;
-constexpr int kBwdKB = 2, kBwdKR = 1, kBwdKN = 6;
-constexpr int kTileKA = 3;  // backward: 16-byte pieces of grad_out / out per thread per batch (a band of >= 4 rows, k = 3: one batch)
-constexpr int kXL = 4;      // left margin of a padded row: image column x sits at row position kXL + x, so that the 4-pixel
-                            // blocks of the NCHW staging start on multiples of four slots (Wp is a multiple of 4)
+constexpr int kTileKQ = 4;   // channel quads a thread stages per chunk (16 registers): a chunk is 4 * G * kTileKQ channels
 
 struct TileGeo {  // by value in kernarg
-  int rb, nb;     // rows per band, bands per image
-  int Wp;         // row stride of the padded band in positions: kXL + W + R rounded up to 4
+  int nb;         // bands per image: band i owns rows [i H / nb, (i + 1) H / nb) — every band at least R + 1 rows
+  int rows;       // padded rows of the largest band = blockDim.z
+  int Wu;         // padded row length W + 2R = blockDim.y
+  int Ppb;        // slab slots per channel quad (>= rows * Wu; the padding spreads the channel groups over the LDS banks)
   int S;          // backward: channel blocks per (image, band)
 };
-__host__ __device__ inline int tile_row_stride(int W, int R) { return (kXL + W + R + 3) & ~3; }
 
 // workgroup id -> (image, item of the image): ids i, i + 8, i + 16, ... share an XCD, so a group of 8 images is dealt one
 // image per XCD and all `per` items (bands x channel blocks) of an image follow each other on it.  Bijective for any B
 // (the last group may hold fewer than 8 images; its placement is then only partly XCD-aligned: speed, not correctness).
 __device__ __forceinline__ void tile_ids(int id, int B, int per, int& b, int& item) {
-  const int grp = id / (8 * per), l = id - grp * 8 * per;   // (once per kernel, wave-uniform: plain integer division)
+  // (wave-uniform, once per workgroup; fdivi: four vector instructions where a scalar integer division takes ~40.
+  // Exact below 2^22 workgroups)
+  const int grp = __builtin_amdgcn_readfirstlane(fdivi(id, 8 * per)), l = id - grp * 8 * per;   // (back to scalar registers)
   const int m = min(8, B - 8 * grp);
-  item = l / m;
+  item = __builtin_amdgcn_readfirstlane(fdivi(l, m));
   b = 8 * grp + l - item * m;
 }
 
-// The band's padded geometry.  Two index spaces: slab POSITIONS u = yy * Wp + kXL + x (rows of stride Wp, margins
-// unused) and the compact USEFUL positions v = yy * Wu + x + R, Wu = W + 2R (ring columns included) that threads and
-// the per-position tables are numbered by.  A tap (dy, dx) is u + dy * Wp + dx resp. v + dy * Wu + dx.
 template <int R>
 struct TileBand {
-  int y0, y1, rows, Wp, Wu, npos, npu, nbp;  // owned rows [y0, y1); staged rows; slab positions; useful positions; band pixels
+  int y0, y1, rows;  // owned rows [y0, y1); padded rows y0 - R .. y1 + R - 1
   __device__ __forceinline__ TileBand(const KP& g, const TileGeo& tg, int band) {
-    y0 = band * tg.rb;
-    y1 = min(g.H, y0 + tg.rb);
+    y0 = __builtin_amdgcn_readfirstlane(fdivi(band * g.H, tg.nb));
+    y1 = __builtin_amdgcn_readfirstlane(fdivi((band + 1) * g.H, tg.nb));
     rows = y1 - y0 + 2 * R;
-    Wp = tg.Wp;
-    Wu = g.W + 2 * R;
-    npos = rows * Wp;
-    npu = rows * Wu;
-    nbp = (y1 - y0) * g.W;
   }
 };
 
 // nn.Conv2d's padding_mode as ARITHMETIC: a coordinate t outside [0, n) maps to a * t + b with per-mode constants (reflect:
 // -t / 2(n-1) - t; replicate: 0 / n-1; zeros: -1 = "reads 0").  nfp_common.h::map_index selects on the mode — a
-// wave-uniform value, which hipcc turns into scalar BRANCHES, five per call; these kernels call it a few dozen times per
-// thread in straight-line setup code, where every taken branch is an instruction-fetch stall (measured: the index work
-// in front of the first load took 2.9 us of a 12.8 us workgroup).  The constants are chosen once per kernel.
+// wave-uniform value, which hipcc turns into scalar BRANCHES, five per call.  The constants are chosen once per kernel.
 struct Fold {
   int a, blo, bhiH, bhiW;
   __device__ __forceinline__ Fold(const KP& g) {
@@ -89,96 +85,71 @@ struct Fold {
   __device__ __forceinline__ int x(int t, int W) const { return t < 0 ? a * t + blo : (t >= W ? a * t + bhiW : t); }
 };
 
-// v or zeros, by component (a ternary between two float4 LVALUES selects an address and forces both into scratch memory)
-__device__ __forceinline__ float4 keep_if(bool in, float x, float y, float z, float w) {
-  return make_float4(in ? x : 0.f, in ? y : 0.f, in ? z : 0.f, in ? w : 0.f);
-}
+// A buffer load whose offset lies beyond the resource's extent returns 0 and touches no memory: positions that read
+// zeros (zero padding, rows past the band) OR this offset into theirs instead of a select per loaded value.  (tile_ok
+// keeps every image below 0x7ffffff0 bytes.  An OR, not a ternary: hipcc turns "zero ? far : computed" into a branch
+// around the computation and then no longer knows that the row stride inside it is wave-uniform — a waterfall loop per
+// load.)
+template <bool BF>
+struct Oob {
+  static constexpr int e = BF ? 0x3ffffff8 : 0x1ffffffc;   // element offset whose byte offset is 0x7ffffff0
+};
 
-// Staging of one channel chunk of the padded band: float4[cq][Ppb], slot swz(u) of slab position u.
-// All loads of a chunk are issued back to back into registers (indices clamped onto valid items, nothing conditional
-// around a load but wave-uniform round checks) and committed to LDS later, so that arithmetic can run under their
-// latency.  What the commit needs to know about an item is kept in one register (its slot | flags): the index
-// arithmetic runs once.
-constexpr int kTileZero = 1 << 30, kTileSkip = 1 << 29, kTileSlot = kTileSkip - 1;
-template <int R, bool BF, bool NHWC, int kTileKB, int kTileKR, int kTileKN>
+// What a thread knows about its padded position.
+template <int R>
+struct TilePos {
+  int gl, vx, vy, v;   // channel group; padded column, padded row; v = vy * Wu + vx
+  int y, x;            // image coordinates (outside the image for ring positions)
+  int src;             // the image pixel the position holds a copy of (clamped into the image when there is none)
+  bool live;           // the row exists in this band (bands differ by a row; blockDim.z is the largest)
+  bool real;           // an image pixel (not a ring position): owns pairs
+  bool zero;           // reads zeros (zero padding; rows past the band)
+  bool own;            // a pixel of the band's own rows: writes outputs
+  int zf, zh;          // `zero` as an offset to OR in: Oob<false>::e / Oob<true>::e, or 0
+  __device__ __forceinline__ TilePos(const KP& g, const TileGeo& tg, const TileBand<R>& bd, const Fold& fo) {
+    gl = threadIdx.x;
+    vx = threadIdx.y;
+    vy = threadIdx.z;
+    v = vy * tg.Wu + vx;
+    y = bd.y0 - R + vy;
+    x = vx - R;
+    live = vy < bd.rows;
+    const int sy = fo.y(y, g.H), sx = fo.x(x, g.W);
+    real = live && (unsigned)y < (unsigned)g.H && (unsigned)x < (unsigned)g.W;
+    zero = !live || (sy | sx) < 0;
+    src = min(max(sy, 0), g.H - 1) * g.W + max(sx, 0);
+    own = real && vy >= R && vy < bd.rows - R;
+    zf = zero ? Oob<false>::e : 0;
+    zh = zero ? Oob<true>::e : 0;
+  }
+  template <bool BF>
+  __device__ __forceinline__ int zoff() const { return BF ? zh : zf; }
+};
+
+// The thread's own position of a channel chunk: quads gl, gl + G, ... (the quads it will sum), every load issued back
+// to back into registers, written to LDS later so that arithmetic can run under their latency.
+template <int R, bool BF, bool NHWC>
 struct TileStage {
-  float4 blk[NHWC ? 1 : kTileKB][4];
-  float4 ring[NHWC ? 1 : kTileKR];
-  float4 nv[NHWC ? kTileKN : 1];
-  int bdst[NHWC ? 1 : kTileKB], bu0[NHWC ? 1 : kTileKB], rdst[NHWC ? 1 : kTileKR], ndst[NHWC ? kTileKN : 1];
-
-  __device__ __forceinline__ void issue(const KP& g, const Fold& fo, const TileBand<R>& bd, Rsrc xb, int Ppb, int c0, int ncq, int t,
-                                        int T) {
-    const int W = g.W, H = g.H, P = g.P, tw = t & ~63;
-    if constexpr (NHWC) {
-      const int items = bd.npu * ncq;
+  float4 q[kTileKQ];
+  __device__ __forceinline__ void issue(const KP& g, const TilePos<R>& ps, Rsrc xb, int G, int c0, int ncq) {
 #pragma unroll
-      for (int k = 0; k < kTileKN; ++k) {
-        ndst[k] = kTileSkip;
-        if (tw + k * T < items) {  // (wave-uniform)
-          const int i = min(t + k * T, items - 1);
-          const int v = fdivi(i, ncq), cq = i - v * ncq;
-          const int yy = fdivi(v, bd.Wu), x = v - yy * bd.Wu - R;
-          const int sy = fo.y(bd.y0 - R + yy, H), sx = fo.x(x, W);
-          nv[k] = load_px4<BF>(xb, (max(sy, 0) * W + max(sx, 0)) * g.C + c0 + 4 * cq, 0);
-          ndst[k] = (cq * Ppb + swz(yy * bd.Wp + kXL + x)) | ((sy | sx) < 0 ? kTileZero : 0) | (t + k * T < items ? 0 : kTileSkip);
-        }
-      }
-    } else {
-      const int nbr = (W + 3) >> 2, per = bd.rows * nbr, nblk = ncq * per;
-#pragma unroll
-      for (int r = 0; r < kTileKB; ++r) {
-        bdst[r] = kTileSkip;
-        bu0[r] = 0;
-        if (tw + r * T < nblk) {
-          const int i = min(t + r * T, nblk - 1);
-          const int cq = fdivi(i, per), rem = i - cq * per, yy = fdivi(rem, nbr), bq = rem - yy * nbr;
-          const int sy = fo.y(bd.y0 - R + yy, H), xs = min(4 * bq, W - 4);
-          const int e = (c0 + 4 * cq) * P + max(sy, 0) * W + xs;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) blk[r][j] = load_px4<BF>(xb, e, j * P);
-          bdst[r] = (cq * Ppb) | (sy < 0 ? kTileZero : 0) | (t + r * T < nblk ? 0 : kTileSkip);
-          bu0[r] = yy * bd.Wp + kXL + xs;
-        }
-      }
-      const int pr = bd.rows * 2 * R, nring = ncq * pr;
-#pragma unroll
-      for (int r = 0; r < kTileKR; ++r) {
-        rdst[r] = kTileSkip;
-        if (tw + r * T < nring) {
-          const int i = min(t + r * T, nring - 1);
-          const int cq = fdivi(i, pr), rem = i - cq * pr, yy = fdivi(rem, 2 * R), k = rem - yy * 2 * R;
-          const int x = k < R ? k - R : W + k - R;   // ring column: -R .. -1, W .. W+R-1
-          const int sy = fo.y(bd.y0 - R + yy, H), sx = fo.x(x, W);
-          const int e = (c0 + 4 * cq) * P + max(sy, 0) * W + max(sx, 0);
-          ring[r] = make_float4(load_1<BF>(xb, e, 0), load_1<BF>(xb, e, P), load_1<BF>(xb, e, 2 * P), load_1<BF>(xb, e, 3 * P));
-          rdst[r] = (cq * Ppb + swz(yy * bd.Wp + kXL + x)) | ((sy | sx) < 0 ? kTileZero : 0) | (t + r * T < nring ? 0 : kTileSkip);
-        }
+    for (int k = 0; k < kTileKQ; ++k) {
+      const int cq = min(ps.gl + k * G, ncq - 1);   // (clamped: nothing conditional around a load)
+      if constexpr (NHWC) {
+        const int e = (ps.src * g.C + c0 + 4 * cq) | ps.template zoff<BF>();
+        q[k] = load_px4<BF>(xb, e, 0);
+      } else {
+        const int e = ((c0 + 4 * cq) * g.P + ps.src) | ps.template zoff<BF>();
+        q[k] = make_float4(load_1<BF>(xb, e, 0), load_1<BF>(xb, e, g.P), load_1<BF>(xb, e, 2 * g.P), load_1<BF>(xb, e, 3 * g.P));
       }
     }
   }
-
-  __device__ __forceinline__ void commit(float4* slab) const {
-    if constexpr (NHWC) {
+  // (a quad past the chunk's end goes to the spare slot `dump`: an address select; a predicated LDS store costs registers)
+  __device__ __forceinline__ void commit(float4* slab, const TilePos<R>& ps, int G, int Ppb, int ncq, int dump) const {
 #pragma unroll
-      for (int k = 0; k < kTileKN; ++k)
-        if (!(ndst[k] & kTileSkip)) slab[ndst[k] & kTileSlot] = keep_if(!(ndst[k] & kTileZero), nv[k].x, nv[k].y, nv[k].z, nv[k].w);
-    } else {
-#pragma unroll
-      for (int r = 0; r < kTileKB; ++r) {
-        if (!(bdst[r] & kTileSkip)) {
-          const bool in = !(bdst[r] & kTileZero);
-          float4* d = slab + (bdst[r] & kTileSlot);
-          const int u0 = bu0[r];
-          d[swz(u0)] = keep_if(in, blk[r][0].x, blk[r][1].x, blk[r][2].x, blk[r][3].x);
-          d[swz(u0 + 1)] = keep_if(in, blk[r][0].y, blk[r][1].y, blk[r][2].y, blk[r][3].y);
-          d[swz(u0 + 2)] = keep_if(in, blk[r][0].z, blk[r][1].z, blk[r][2].z, blk[r][3].z);
-          d[swz(u0 + 3)] = keep_if(in, blk[r][0].w, blk[r][1].w, blk[r][2].w, blk[r][3].w);
-        }
-      }
-#pragma unroll
-      for (int r = 0; r < kTileKR; ++r)
-        if (!(rdst[r] & kTileSkip)) slab[rdst[r] & kTileSlot] = keep_if(!(rdst[r] & kTileZero), ring[r].x, ring[r].y, ring[r].z, ring[r].w);
+    for (int k = 0; k < kTileKQ; ++k) {
+      const int cq = ps.gl + k * G;
+      slab[cq < ncq ? cq * Ppb + ps.v : dump] = q[k];
     }
   }
 };
@@ -194,46 +165,35 @@ __device__ __forceinline__ float wave_sum(float v) {
 // ---- forward ----------------------------------------------------------------------------------------------------------
 // POOL: the fused tail of models/NFP_Pooling.py:27-31 for large maps: besides the maps this band's share of the two
 // pooled sums goes to part[(b * nb + band)][C + N] (sums, not means); pool_fold joins the bands in a fixed order.
-// (k = 3: two workgroups of up to 1024 threads share a compute unit — 8 wavefronts per SIMD, 64 registers; k = 5 keeps
-// twelve sums and offsets per thread: its launcher caps the workgroup at 512 threads instead)
-template <int R, int M, bool BF, bool NHWC, bool POOL = false>
+// GFC (nfp.py:265-276) differs from cosine in how a pair sum and the two norms combine (a reciprocal per output).
+// LDS: slab [Cc / 4][Ppb] float4 | pair sums [NF][npu] | per-position factor [npu] (| POOL: the band's maps [N][nbp]).
+// (k = 3: two workgroups of up to 1024 threads share a compute unit — 8 wavefronts per SIMD, 64 registers)
+template <int R, int M, bool BF, bool NHWC, bool POOL = false, bool GFC = false>
 __global__ void __launch_bounds__(1024, (R == 1 ? 8 : 4)) fwd_tile(const KP g, const TileGeo tg, const void* __restrict__ x,
                                                  void* __restrict__ out, float* __restrict__ saved,
                                                  float* __restrict__ part) {
   constexpr int N = Win<R>::N, NF = Win<R>::NF;
   constexpr int ES = BF ? 2 : 4;
   extern __shared__ __attribute__((aligned(16))) float4 lds4[];
-  const int t = threadIdx.x, T = blockDim.x;
   int b, band;
   tile_ids(blockIdx.x, g.B, tg.nb, b, band);
   const TileBand<R> bd(g, tg, band);
   const Fold fo(g);
-  const int W = g.W, P = g.P, Wp = bd.Wp, Wu = bd.Wu, npu = bd.npu, nbp = bd.nbp;
-  const int G = g.G, lg = g.Tc;
-  const int Ppb = band_row_slots(bd.npos, lg);   // (npos is a multiple of 4)
+  const TilePos<R> ps(g, tg, bd, fo);
+  const int G = blockDim.x, Wu = tg.Wu, Ppb = tg.Ppb, npu = tg.rows * Wu;
+  const int W = g.W, P = g.P, v = ps.v;
   float4* slab = lds4;
-  float* Tt = (float*)(lds4 + (g.Cc >> 2) * Ppb);  // [NF + 1][npu]: pair sums per direction, then |x|^2
+  const int dump = (g.Cc >> 2) * Ppb;               // (a spare slot behind the slab)
+  float* Tt = (float*)(lds4 + dump + 1);            // [NF][npu] pair sums per direction, then the per-position factor
+  float* Fq = Tt + NF * npu;
   const Rsrc xb = make_rsrc((const char*)x + (long long)b * g.sB * ES, (long long)g.C * P * ES);
   NFP_STAMP_INIT();
   NFP_STAMP(0);
 
-  TileStage<R, BF, NHWC, kFwdKB, kFwdKR, kFwdKN> st;
-  st.issue(g, fo, bd, xb, Ppb, 0, min(g.Cc, g.C) >> 2, t, T);
+  TileStage<R, BF, NHWC> st;
+  st.issue(g, ps, xb, G, 0, min(g.Cc, g.C) >> 2);
   __builtin_amdgcn_sched_barrier(0);
 
-  // channel sums: thread t = useful position * G + group (the groups of a position are adjacent lanes: joined by DPP)
-  const int gl = t & (G - 1), vc = t >> lg;
-  const bool active = vc < npu;
-  const int v = min(vc, npu - 1), vy = fdivi(v, Wu), vx = v - vy * Wu;
-  const int u = vy * Wp + kXL - R + vx, su = swz(u);
-  int off[NF];
-#pragma unroll
-  for (int d = 0; d < NF; ++d) {
-    int dy, dx;
-    fdir<R>(d, dy, dx);
-    const bool ok = vx + dx >= 0 && vx + dx < Wu && vy + dy < bd.rows;
-    off[d] = ok ? swz(u + dy * Wp + dx) - su : 0;
-  }
   float acc[NF];
 #pragma unroll
   for (int d = 0; d < NF; ++d) acc[d] = 0.f;
@@ -243,40 +203,62 @@ __global__ void __launch_bounds__(1024, (R == 1 ? 8 : 4)) fwd_tile(const KP g, c
   for (int c0 = 0; c0 < g.C; c0 += g.Cc) {
     const int ncq = min(g.Cc, g.C - c0) >> 2;
     if (c0 > 0) __syncthreads();  // previous chunk fully consumed
-    st.commit(slab);
+    st.commit(slab, ps, G, Ppb, ncq, dump);
     __syncthreads();
     // the next chunk's loads fly while this one is summed (the staging registers are free once committed)
-    if (c0 + g.Cc < g.C) st.issue(g, fo, bd, xb, Ppb, c0 + g.Cc, min(g.Cc, g.C - c0 - g.Cc) >> 2, t, T);
+    if (c0 + g.Cc < g.C) st.issue(g, ps, xb, G, c0 + g.Cc, min(g.Cc, g.C - c0 - g.Cc) >> 2);
     if (c0 == 0) NFP_STAMP(2);
     if constexpr (POOL) {
       // this band's share of sum over pixels of x[c]: wavefront w takes channel quads w, w + nw, ...; lanes stride over
-      // the band's pixels; fixed DPP tree; one writer per channel
-      const int lane = t & 63, wv = t >> 6, nw = T >> 6;
-      for (int cq = wv; cq < ncq; cq += nw) {
-        float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int lp = lane; lp < nbp; lp += 64) {
-          const int yl = fdivi(lp, W), xl = lp - yl * W;
-          const float4 q = slab[cq * Ppb + swz((yl + R) * Wp + kXL + xl)];
-          s4.x += q.x;
-          s4.y += q.y;
-          s4.z += q.z;
-          s4.w += q.w;
+      // the band's pixels; fixed DPP tree; one writer per channel.  (FULL wavefronts only: the tree reads all 64 lanes;
+      // a workgroup's last wavefront may be partial)
+      const int t = ps.gl + G * v, lane = t & 63, wv = t >> 6, nw = (G * npu) >> 6;
+      const int nbp = (bd.y1 - bd.y0) * W;
+      float* pb = part + ((long long)b * tg.nb + band) * (g.C + N) + c0;
+      if (wv < nw) {
+        for (int cq = wv; cq < ncq; cq += nw) {
+          float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
+          for (int lp = lane; lp < nbp; lp += 64) {
+            const int yl = fdivi(lp, W), xl = lp - yl * W;
+            const float4 q = slab[cq * Ppb + (yl + R) * Wu + xl + R];
+            s4.x += q.x;
+            s4.y += q.y;
+            s4.z += q.z;
+            s4.w += q.w;
+          }
+          s4.x = wave_sum(s4.x);
+          s4.y = wave_sum(s4.y);
+          s4.z = wave_sum(s4.z);
+          s4.w = wave_sum(s4.w);
+          if (lane == 63) *(float4*)(pb + 4 * cq) = s4;
         }
-        s4.x = wave_sum(s4.x);
-        s4.y = wave_sum(s4.y);
-        s4.z = wave_sum(s4.z);
-        s4.w = wave_sum(s4.w);
-        if (lane == 63) *(float4*)(part + ((long long)b * tg.nb + band) * (g.C + N) + c0 + 4 * cq) = s4;
+      } else if (nw == 0 && t == 0) {  // (a workgroup below 64 threads: tiny maps, one thread adds them up)
+        for (int cq = 0; cq < ncq; ++cq) {
+          float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
+          for (int lp = 0; lp < nbp; ++lp) {
+            const int yl = lp / W, xl = lp - yl * W;
+            const float4 q = slab[cq * Ppb + (yl + R) * Wu + xl + R];
+            s4.x += q.x;
+            s4.y += q.y;
+            s4.z += q.z;
+            s4.w += q.w;
+          }
+          *(float4*)(pb + 4 * cq) = s4;
+        }
       }
     }
-    if (active) {
-      for (int cq = gl; cq < ncq; cq += G) {
-        const float4* row = slab + cq * Ppb + su;
-        const float4 a = row[0];
+    if (ps.live) {
+      // (every tap at a constant offset; a tap past the padded band reads whatever lies there: such a pair is never
+      // looked up)
+      for (int cq = ps.gl; cq < ncq; cq += G) {
+        const float4* r0 = slab + cq * Ppb + v;
+        const float4 a = r0[0];
         nrm = fmaf(a.x, a.x, fmaf(a.y, a.y, fmaf(a.z, a.z, fmaf(a.w, a.w, nrm))));
 #pragma unroll
         for (int d = 0; d < NF; ++d) {
-          const float4 q = row[off[d]];
+          int dy, dx;
+          fdir<R>(d, dy, dx);
+          const float4 q = dy == 0 ? r0[dx] : (r0 + dy * Wu - R)[dx + R];   // (row base + compile-time column)
           if (M == NFP_COSINE) {
             acc[d] = fmaf(a.x, q.x, fmaf(a.y, q.y, fmaf(a.z, q.z, fmaf(a.w, q.w, acc[d]))));
           } else {
@@ -288,63 +270,89 @@ __global__ void __launch_bounds__(1024, (R == 1 ? 8 : 4)) fwd_tile(const KP g, c
     }
   }
   NFP_STAMP(3);
-  // channel groups joined inside the wavefront; one lane per position publishes the sums
+  // channel groups joined inside the wavefront; one lane per position publishes the sums.  The per-position factor F:
+  // cosine 1 / max(|x|, eps), DotProduct 1, GFC |x| itself; L2 keeps |x|^2 (the 'Norm' quirk reads it).
 #pragma unroll
   for (int d = 0; d < NF; ++d) acc[d] = group_sum(acc[d], G);
   nrm = group_sum(nrm, G);
-  if (active && gl == G - 1) {
+  if (G > 16) {  // (group_sum leaves the sum in the group's last lane only: hand it to the others — they share the outputs)
+    const int last = (__lane_id() | (G - 1)) << 2;
+#pragma unroll
+    for (int d = 0; d < NF; ++d) acc[d] = __int_as_float(__builtin_amdgcn_ds_bpermute(last, __float_as_int(acc[d])));
+    nrm = __int_as_float(__builtin_amdgcn_ds_bpermute(last, __float_as_int(nrm)));
+  }
+  const float Fp = M == NFP_COSINE ? (GFC ? __builtin_amdgcn_sqrtf(nrm) : unit_or(g, inv_norm(nrm, g.inv_eps))) : nrm;
+  if (ps.gl == 0) {
 #pragma unroll
     for (int d = 0; d < NF; ++d) Tt[d * npu + v] = acc[d];
-    Tt[NF * npu + v] = nrm;
+    Fq[v] = Fp;
   }
   __syncthreads();
   NFP_STAMP(4);
-  // outputs of the band's rows: thread (pixel, n = glf, glf + Gn, ...), lanes along pixels (coalesced stores)
-  const float* n2 = Tt + NF * npu;
-  const int glf = fdivi(t, nbp), lpf = t - glf * nbp, Gn = fdivi(T, nbp);
-  float* vm = Tt + (NF + 1) * npu;  // (POOL) [N][nbp]: the band's map values, for the pooled sums
-  if (glf < Gn) {
-    const int yl = fdivi(lpf, W), xl = lpf - yl * W, pv = (yl + R) * Wu + xl + R;
-    const int p = (bd.y0 + yl) * W + xl;
-    void* ob = (char*)out + (long long)b * N * P * ES;
-    const float n2p = n2[pv];
-    const float ip = unit_or(g, inv_norm(n2p, g.inv_eps));
-    auto one = [&](int n) {
+  // outputs of the band's rows, by the position's own threads (lanes along a row: coalesced stores); the G lanes of a
+  // position share the N taps
+  const int nbpA = (tg.rows - 2 * R) * W, lpf = (ps.vy - R) * W + ps.x;
+  float* vm = Fq + npu;  // (POOL) [N][nbpA]: the band's map values, for the pooled sums
+  if (ps.own) {
+    const int p = ps.y * W + ps.x;
+    // (buffer stores: one offset register for all N maps of the pixel, the map through the scalar offset)
+    const Rsrc ob = make_rsrc((char*)out + (long long)b * N * P * ES, (long long)N * P * ES);
+    auto one = [&](int n, auto statc) {
+      constexpr bool stat = decltype(statc)::value;
       int dy, dx;
       tap_offset<R>(n, dy, dx);
       const bool fwd = dy > 0 || (dy == 0 && dx > 0);
       const int fi = fwd ? fidx<R>(dy, dx) : fidx<R>(-dy, -dx);
-      const int qv = pv + dy * Wu + dx;
-      const float pairv = Tt[fi * npu + (fwd ? pv : qv)];
-      const float n2q = n2[qv];
+      const float* rq = Fq + v + dy * Wu - R;
+      const float fq = rq[dx + R];
+      // (one lane per position and a forward tap: the pair sum is still in this thread's registers)
+      float pairv;
+      if constexpr (stat)
+        pairv = fwd ? acc[fi] : (Tt + fi * npu + v + dy * Wu - R)[dx + R];
+      else
+        pairv = Tt[fi * npu + (fwd ? v : v + dy * Wu + dx)];
       float val;
       if (M == NFP_COSINE) {
-        const float s = prod_value(g, pairv, n2p, n2q, ip, unit_or(g, inv_norm(n2q, g.inv_eps)));
+        const float s = GFC ? pairv * __builtin_amdgcn_rcpf(fmaf(Fp, fq, g.eps)) : pairv * Fp * fq;
         val = fin_prod(g, s);
       } else {
-        val = fin_dist(g, g.diff ? pairv : n2q);  // 'Norm' quirk (nfp.py:74 vs 85): |neighbour|
+        val = fin_dist(g, g.diff ? pairv : fq);  // 'Norm' quirk (nfp.py:74 vs 85): |neighbour|
       }
-      stx(ob, n * P + p, val, BF ? NFP_BF16 : NFP_F32);
-      if constexpr (POOL) vm[n * nbp + lpf] = val;
+      if constexpr (stat)
+        store_1<BF>(ob, p, n * P, val);
+      else
+        store_1<BF>(ob, n * P + p, 0, val);
+      if constexpr (POOL) vm[n * nbpA + lpf] = val;
     };
-    if (Gn == 1) {  // (the usual case on large maps: every tap's offsets are compile-time constants)
+    if (G == 1) {  // (the usual case on large maps: every tap's offsets are compile-time constants)
 #pragma unroll
-      for (int n = 0; n < N; ++n) one(n);
+      for (int n = 0; n < N; ++n) one(n, std::true_type{});
     } else {
-      for (int n = glf; n < N; n += Gn) one(n);
+      for (int n = ps.gl; n < N; n += G) one(n, std::false_type{});
     }
-    if (M == NFP_COSINE && !g.unit && saved != nullptr && glf == 0) saved[(long long)b * P + p] = __builtin_amdgcn_sqrtf(n2p);
+    if (M == NFP_COSINE && !g.unit && saved != nullptr && ps.gl == 0)
+      saved[(long long)b * P + p] = GFC ? Fp : __builtin_amdgcn_sqrtf(nrm);
   }
   if constexpr (POOL) {
     // this band's share of sum over pixels of out[n]: wavefront w reduces map n = w, w + nw, ... over the band's pixels
     // in a fixed order
     __syncthreads();
-    const int lane = t & 63, wv = t >> 6, nw = T >> 6;
-    for (int n = wv; n < N; n += nw) {
-      float s = 0.f;
-      for (int i = lane; i < nbp; i += 64) s += vm[n * nbp + i];
-      s = wave_sum(s);
-      if (lane == 63) part[((long long)b * tg.nb + band) * (g.C + N) + g.C + n] = s;
+    const int t = ps.gl + G * v, lane = t & 63, wv = t >> 6, nw = (G * npu) >> 6;
+    const int nbp = (bd.y1 - bd.y0) * W;
+    float* pb = part + ((long long)b * tg.nb + band) * (g.C + N) + g.C;
+    if (wv < nw) {
+      for (int n = wv; n < N; n += nw) {
+        float s = 0.f;
+        for (int i = lane; i < nbp; i += 64) s += vm[n * nbpA + i];
+        s = wave_sum(s);
+        if (lane == 63) pb[n] = s;
+      }
+    } else if (nw == 0 && t == 0) {
+      for (int n = 0; n < N; ++n) {
+        float s = 0.f;
+        for (int i = 0; i < nbp; ++i) s += vm[n * nbpA + i];
+        pb[n] = s;
+      }
     }
   }
   NFP_STAMP(5);
@@ -369,197 +377,165 @@ __global__ void __launch_bounds__(256) pool_fold(const float* __restrict__ part,
 // POOL: grad_out is not a map: go[b,n,p] = gnfpm[b,n] / P for every p, and every grad_x[b,c,p] also gets ggap[b,c] / P.
 // GFC: the general post-factors of nfp_common.h::cross_f / diag_f (a reciprocal per window slot); cosine and dot keep the
 // plain product of the two per-pixel factors.
+// LDS (floats): ipn [PL] | pair values [N][PL] (cosine: sg = +-grad_out; L2: c = -+g / d) — PL = (rows + 2R) * Wu: R
+// rows of ZEROS above and below the band in every plane, so that a tap at a constant offset of ANY position reads a
+// value (a column past the row's end lands in the ring columns of the next row: zeros too).  After phase A the pair
+// values are dead: the x slab lies over them, and behind the slab the window rows of the ring positions [npu][K2].
+// (Cosine: the pair {r, r + d} has ONE similarity s, which reaches the backward twice — out[n][r] and
+// out[opp n][r + d], equal up to the forward's rounding; the pull of both on |x_r| uses r's own copy, so that only the
+// gradients travel through LDS.)
 template <int R, int M, bool BF, bool NHWC, bool POOL = false, bool GFC = false>
-__global__ void __launch_bounds__(512) bwd_tile(const KP g, const TileGeo tg, const void* __restrict__ x,
+__global__ void __launch_bounds__(1024, (R == 1 ? 8 : 4)) bwd_tile(const KP g, const TileGeo tg, const void* __restrict__ x,
                                                 const void* __restrict__ go, const void* __restrict__ out,
                                                 const float* __restrict__ saved, void* __restrict__ gx,
                                                 const float* __restrict__ ggap, const float* __restrict__ gnfpm) {
   constexpr int N = Win<R>::N, K = Win<R>::K, K2 = Win<R>::K2;
   constexpr int ES = BF ? 2 : 4;
   extern __shared__ __attribute__((aligned(16))) float4 lds4[];
-  const int t = threadIdx.x, T = blockDim.x;
   int b, item;
   tile_ids(blockIdx.x, g.B, tg.nb * tg.S, b, item);
   const int band = item / tg.S, cblk = item - band * tg.S;
   const TileBand<R> bd(g, tg, band);
   const Fold fo(g);
-  const int W = g.W, H = g.H, P = g.P, Wp = bd.Wp, Wu = bd.Wu, npu = bd.npu, nbp = bd.nbp;
-  const int ya = max(0, bd.y0 - R), yb = min(H, bd.y1 + R), npA = (yb - ya) * W;  // rows whose pairs touch the band
+  const TilePos<R> ps(g, tg, bd, fo);
+  const int G = blockDim.x, Wu = tg.Wu, Ppb = tg.Ppb, PL = (tg.rows + 2 * R) * Wu;
+  const int W = g.W, H = g.H, P = g.P, v = ps.v;
   const int cb0 = cblk * g.Cwg, cb1 = min(g.C, cb0 + g.Cwg);
-  // LDS: ipn [npu] | dfn [nbp] | pair values [N][npA] — and the x slab over the pair values.  (The window weights never
-  // go through LDS: the thread that builds a pixel's row in phase A is the thread that uses it in phase B; with several
-  // channel groups per pixel every group builds the row for itself.)
-  float* ipn = (float*)lds4;
-  float* dfn = ipn + npu;
-  float4* pv4 = lds4 + ((npu + nbp + 3) >> 2);
-  float2* AD = (float2*)pv4;  // cosine: {sg, sg * s}
-  float* CC = (float*)pv4;    // L2: c = -+g / d
-  float4* slab = pv4;
-  const int Ppb = bd.npos | 1;
+  float* ipn = (float*)lds4 + R * Wu;                       // ipn[v], margins at v < 0 and v >= npu
+  float* pvb = (float*)lds4 + ((PL + 3) & ~3);
+  float* PV = pvb + R * Wu;                                 // plane n at PV + n * PL
+  float4* slab = (float4*)pvb;
+  const int dump = (g.Cc >> 2) * Ppb;                       // (a spare slot behind the slab)
+  float* Wr = (float*)(slab + dump + 1) + 2 * K2;           // (2 K2 floats of slack either side: shifted reads)
   const Rsrc xb = make_rsrc((const char*)x + (long long)b * g.sB * ES, (long long)g.C * P * ES);
   const Rsrc gxb = make_rsrc((char*)gx + (long long)b * g.gB * ES, (long long)g.C * P * ES);
+  const Rsrc gob = make_rsrc((const char*)go + (long long)b * N * P * ES, POOL ? 0 : (long long)N * P * ES);
+  const Rsrc outb = make_rsrc((const char*)out + (long long)b * N * P * ES, (long long)N * P * ES);
+  // (DotProduct has no saved norms: an empty resource, every load reads 0)
+  const Rsrc svb = make_rsrc((const char*)saved + (long long)b * P * 4, (M == NFP_COSINE && !g.unit) ? (long long)P * 4 : 0);
   NFP_STAMP_INIT();
   NFP_STAMP(0);
 
-  // ---- A1: per-pair values of the rows ya .. yb-1, every tap; norm factors of every useful padded position ----------
-  // Every load of a batch is issued before the first value is used (16-byte pieces of grad_out / out, the saved norms),
-  // then the x chunk is requested, so that the pair arithmetic runs while x streams in.
-  TileStage<R, BF, NHWC, kBwdKB, kBwdKR, kBwdKN> st;
+  // ---- A1: the position's own pairs (every tap), its norm factor; all loads first, then the x chunk ----------------
+  // A position that owns no pairs (ring, outside the image, rows past the band) loads zeros: its pair values come out 0.
+  TileStage<R, BF, NHWC> st;
+  float w[K2], sv[N];
+  float dfn = 0.f, ipr = 1.f;
   {
-    const char* gob = (const char*)go + ((long long)b * N * P + (long long)ya * W) * ES;
-    const char* outb = (const char*)out + ((long long)b * N * P + (long long)ya * W) * ES;
+    const int ep = ps.real ? ps.y * W + ps.x : Oob<BF>::e;
+    float gov[N];
+    // Cosine: a RING position needs the similarity of every pair that ends on it — the output of its real neighbour's
+    // opposite tap (plane N-1-n at pixel u + d_n).  Same load instruction as everybody's own outputs: the plane
+    // difference and the tap offset go into the ring lanes' address (a mask, not a branch around a load).
+    const bool ring = M == NFP_COSINE && ps.live && !ps.real && !ps.zero;
+    const int ea = ring ? ps.y * W + ps.x : ep, rm = ring ? -1 : 0;
+    bool rbad[K], cbad[K];
+#pragma unroll
+    for (int d = 0; d < K; ++d) {
+      rbad[d] = ring && (unsigned)(ps.y + d - R) >= (unsigned)H;
+      cbad[d] = ring && (unsigned)(ps.x + d - R) >= (unsigned)W;
+    }
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+      const int j = n < K2 / 2 ? n : n + 1, dy = j / K - R, dx = j % K - R;
+      // (the plane goes into the lane's own offset: the range check of a buffer load looks at that offset alone, and a
+      // ring lane's "plane difference" may be negative)
+      int e = ep + n * P;
+      if (M == NFP_COSINE) {
+        e = ea + n * P + (((N - 1 - 2 * n) * P + dy * W + dx) & rm);
+        e = (rbad[dy + R] || cbad[dx + R]) ? Oob<BF>::e : e;
+      }
+      sv[n] = load_1<BF>(outb, e, 0);
+      gov[n] = POOL ? 0.f : load_1<BF>(gob, ep, n * P);
+    }
+    float nrm = 0.f;
+    if (M == NFP_COSINE) nrm = load_1<false>(svb, ps.src | ps.zf, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    st.issue(g, ps, xb, G, cb0, min(g.Cc, cb1 - cb0) >> 2);
+    __builtin_amdgcn_sched_barrier(0);
+    NFP_STAMP(7);
     // (the sign convention as arithmetic: a select on a wave-uniform flag becomes a branch per value)
     const float sa = g.osa, sb = -g.osa * g.osb;   // s = osa * (out - osb): out = osa * s + osb with osa = +-1
-    auto put = [&](int i, float gc, float oc) {
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+      const int j = n < K2 / 2 ? n : n + 1;
+      float gc = gov[n];
+      if constexpr (POOL) gc = ps.real ? gnfpm[(long long)b * N + n] * g.invP : 0.f;
       if (M == NFP_COSINE) {
-        const float s = fmaf(sa, oc, sb);
-        const float sg = sa * gc;
-        AD[i] = make_float2(sg, sg * s);
+        sv[n] = fmaf(sa, sv[n], sb);
+        w[j] = sa * gc;
       } else {
-        CC[i] = dist_coef(g, gc, oc);
+        w[j] = ps.real ? dist_coef(g, gc, sv[n]) : 0.f;
       }
-    };
-    // saved norms of the useful padded positions (ring positions read their fold source)
-    constexpr int KS = 2;   // (a band of >= 3 rows has at most 2 T useful positions; more: the loop behind)
-    float nrmv[KS];
-    // (every load unconditional, on an index clamped into range: a load under a branch, or one that overwrites an
-    // initialised register, makes hipcc wait for it where the paths join.  Issue order = the order the data is needed in:
-    // pair values, the x chunk, the norms — loads retire in order.)
-    // (DotProduct has no saved norms: its loads read the output map instead — in bounds, unused — rather than sit
-    // under a branch)
-    const float* sv = g.unit ? (const float*)out : saved;
-    auto norm_loads = [&]() {
-      if (M == NFP_COSINE) {
-#pragma unroll
-        for (int k = 0; k < KS; ++k) {
-          const int v = min(t + k * T, npu - 1), vy = fdivi(v, Wu), vx = v - vy * Wu;
-          const int sy = fo.y(bd.y0 - R + vy, H), sx = fo.x(vx - R, W);
-          nrmv[k] = sv[(long long)b * P + max(sy, 0) * W + max(sx, 0)];
-        }
-      }
-    };
-    auto norms_put = [&](int v, float nrm_raw) {
-      const int vy = fdivi(v, Wu), vx = v - vy * Wu;
-      const int sy = fo.y(bd.y0 - R + vy, H), sx = fo.x(vx - R, W);
-      const float nrm = (sy | sx) < 0 ? 0.f : nrm_raw;
-      const float ip = unit_or(g, __builtin_amdgcn_rcpf(fmaxf(nrm, g.eps)));   // (DotProduct: no norm factors, no diagonal)
-      ipn[v] = GFC ? nrm : ip;                                                  // (GFC: the norm itself — nfp_common.h::cross_f)
-      const int yl = vy - R, xl = vx - R;
-      if (yl >= 0 && yl < bd.y1 - bd.y0 && xl >= 0 && xl < W)
-        dfn[yl * W + xl] = nrm > 0.f ? -(GFC ? 1.f : g.nuf * ip) * __builtin_amdgcn_rcpf(nrm) : 0.f;
-    };
-    constexpr int VP = BF ? 8 : 4;  // values per 16-byte piece
-    bool x_asked = false;
-    if (((P | W) & (VP - 1)) == 0) {
-      const int nseg = npA / VP, tot = N * nseg;
-      for (int base = 0; base < tot; base += kTileKA * T) {
-        uint4 gq[kTileKA], oq[kTileKA];
-#pragma unroll
-        for (int k = 0; k < kTileKA; ++k) {
-          const int i = min(base + t + k * T, tot - 1), n = fdivi(i, nseg), q = i - n * nseg;
-          const long long src = ((long long)n * P + (long long)q * VP) * ES;
-          if constexpr (!POOL) gq[k] = *(const uint4*)(gob + src);
-          oq[k] = *(const uint4*)(outb + src);
-        }
-        if (!x_asked) {
-          __builtin_amdgcn_sched_barrier(0);
-          st.issue(g, fo, bd, xb, Ppb, cb0, min(g.Cc, cb1 - cb0) >> 2, t, T);
-          __builtin_amdgcn_sched_barrier(0);
-          x_asked = true;
-          norm_loads();
-          __builtin_amdgcn_sched_barrier(0);
-          NFP_STAMP(7);
-        }
-#pragma unroll
-        for (int k = 0; k < kTileKA; ++k) {
-          const int i = base + t + k * T;
-          if (i < tot) {
-            const int n = fdivi(i, nseg), q = i - n * nseg;
-            const float gp = POOL ? gnfpm[(long long)b * N + n] * g.invP : 0.f;
-            float gcv[VP], ocv[VP];
-#pragma unroll
-            for (int e = 0; e < VP; ++e) {
-              const uint32_t gw = POOL ? 0u : ((const uint32_t*)&gq[k])[BF ? e >> 1 : e], ow = ((const uint32_t*)&oq[k])[BF ? e >> 1 : e];
-              gcv[e] = POOL ? gp : (BF ? __uint_as_float(e & 1 ? gw & 0xFFFF0000u : gw << 16) : __uint_as_float(gw));
-              ocv[e] = BF ? __uint_as_float(e & 1 ? ow & 0xFFFF0000u : ow << 16) : __uint_as_float(ow);
-            }
-            const int i0 = n * npA + q * VP;   // (a multiple of 4: 16-byte LDS writes, two cosine pairs / four L2 values each)
-            if (M == NFP_COSINE) {
-#pragma unroll
-              for (int e = 0; e < VP; e += 2) {
-                const float s0 = fmaf(sa, ocv[e], sb), g0 = sa * gcv[e], s1 = fmaf(sa, ocv[e + 1], sb), g1 = sa * gcv[e + 1];
-                *(float4*)(AD + i0 + e) = make_float4(g0, g0 * s0, g1, g1 * s1);
-              }
-            } else {
-#pragma unroll
-              for (int e = 0; e < VP; e += 4) {
-                float c4[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) c4[u] = dist_coef(g, gcv[e + u], ocv[e + u]);
-                *(float4*)(CC + i0 + e) = make_float4(c4[0], c4[1], c4[2], c4[3]);
-              }
-            }
-          }
-        }
-      }
-    } else {
-      st.issue(g, fo, bd, xb, Ppb, cb0, min(g.Cc, cb1 - cb0) >> 2, t, T);
-      x_asked = true;
-      norm_loads();
-      for (int i = t; i < N * npA; i += T) {
-        const int n = fdivi(i, npA), l = i - n * npA;
-        const long long src = (long long)n * P + l;
-        const float gc = POOL ? gnfpm[(long long)b * N + n] * g.invP : ldx(gob, src, BF ? NFP_BF16 : NFP_F32);
-        put(i, gc, ldx(outb, src, BF ? NFP_BF16 : NFP_F32));
-      }
+      PV[n * PL + v] = w[j];
     }
-    NFP_STAMP(8);
     if (M == NFP_COSINE) {
+      const float ip = unit_or(g, __builtin_amdgcn_rcpf(fmaxf(nrm, g.eps)));   // (DotProduct: no norm factors, no diagonal)
+      ipr = GFC ? nrm : ip;                                                     // (GFC: the norm itself — nfp_common.h::cross_f)
+      ipn[v] = ipr;
+      dfn = nrm > 0.f ? -(GFC ? 1.f : g.nuf * ip) * __builtin_amdgcn_rcpf(nrm) : 0.f;
+    }
+    // the zero rows above and below the band, every plane
+    if (ps.vy < R || ps.vy >= tg.rows - R) {
+      const int m = ps.vy < R ? v - R * Wu : v + R * Wu;
+      if (M == NFP_COSINE) ipn[m] = 0.f;
 #pragma unroll
-      for (int k = 0; k < KS; ++k)
-        if (t + k * T < npu) norms_put(t + k * T, nrmv[k]);
-      for (int v = t + KS * T; v < npu; v += T) {   // (bands with more than KS * T useful positions)
-        const int vy = fdivi(v, Wu), vx = v - vy * Wu;
-        const int sy = fo.y(bd.y0 - R + vy, H), sx = fo.x(vx - R, W);
-        norms_put(v, sv[(long long)b * P + max(sy, 0) * W + max(sx, 0)]);
-      }
+      for (int n = 0; n < N; ++n) PV[n * PL + m] = 0.f;
     }
   }
   NFP_STAMP(1);
   __syncthreads();
   NFP_STAMP(2);
 
+  // ---- A2: the window weights of this thread's position, in registers (the same code for every position) -------------
   const float dneg = g.diff ? -1.f : 0.f;   // L2: cross weight = -c with the difference weights, 0 with the 'Norm' quirk
-  // ---- A2: the window weights of this thread's pixel, in registers (fixed order; bitwise reproducible) -----------------
-  const int gl = fdivi(t, nbp), lp = t - gl * nbp;
-  const bool active = gl < g.G;
-  const int yl = fdivi(lp, W), xx = lp - yl * W, y = bd.y0 + yl;
-  const int pos = (yl + R) * Wp + kXL + xx, sp = swz(pos);
-  const int p = y * W + xx;
-  float w[K2];
-  auto crossw = [&](float fr, float ft) { return GFC ? cross_f(g, fr, ft) : fr * ft; };
-  auto diagw = [&](float fr, float ft) { return GFC ? diag_f(g, fr, ft) : 1.f; };
-  if (active) {
-    const int pv = (yl + R) * Wu + xx + R, lpA = (y - ya) * W + xx;
-    const float ipr = M == NFP_COSINE ? ipn[pv] : 1.f;
-    float Dsum = 0.f;
-    // Pixels within R of the image border also collect the pairs whose neighbour is a RING position that folds onto them
-    // (reflect / replicate).  By the pixel's own thread: a wavefront with a border pixel pays one trip of the loop below
-    // per valid ring position (an edge pixel has one, a corner three) while the other wavefronts do the same for theirs;
-    // as a pass of its own over the band's border pixels it kept one wavefront busy for 5.5k cycles with the rest of the
-    // workgroup parked at a barrier.
-    float wl[K2];   // what the ring adds to the pixel's window, summed in registers (one LDS update per slot at the end)
+  float D = 0.f;
 #pragma unroll
-    for (int j = 0; j < K2; ++j) wl[j] = 0.f;
+  for (int n = 0; n < N; ++n) {
+    const int j = n < K2 / 2 ? n : n + 1, dy = j / K - R, dx = j % K - R, opp = N - 1 - n;
+    const float c2 = (PV + opp * PL + v + dy * Wu - R)[dx + R];
+    if (M == NFP_COSINE) {
+      const float ipq = (ipn + v + dy * Wu - R)[dx + R];
+      const float S = w[j] + c2;
+      if (GFC) {
+        D = fmaf(S * sv[n], diag_f(g, ipr, ipq), D);
+        w[j] = cross_f(g, ipr, ipq) * S;
+      } else {
+        D = fmaf(S, sv[n], D);
+        w[j] = ipr * ipq * S;
+      }
+    } else {
+      const float c1 = w[j];
+      D += fmaf(-dneg, c1, c2);  // 'Norm' quirk (nfp.py:74 vs 85): only the pair's NEIGHBOUR is pulled
+      w[j] = dneg * (c1 + c2);
+    }
+  }
+  w[K2 / 2] = (M == NFP_COSINE ? dfn : 1.f) * D;
+  NFP_STAMP(9);
+  __syncthreads();  // the pair values are dead: their LDS becomes the x slab
+  NFP_STAMP(3);
+
+  st.commit(slab, ps, G, Ppb, min(g.Cc, cb1 - cb0) >> 2, dump);
+  // A ring position is a copy of the image pixel it folds onto (reflect / replicate): its window row goes to LDS for
+  // that pixel's thread
+  if (ps.live && !ps.real && ps.gl == 0) {
+#pragma unroll
+    for (int j = 0; j < K2; ++j) Wr[v * K2 + j] = w[j];
+  }
+  __syncthreads();
+  NFP_STAMP(4);
+  if (ps.own) {
     // ring positions that fold onto this pixel: per axis the coordinate itself (bit 0) and up to 2R ring coordinates;
     // a bit mask of the valid (row, column) combinations, then one trip per VALID combination (an edge pixel has one,
-    // a corner three) — not a loop over all (2R+1)^2 with a dozen scalar branches each
+    // a corner three) — wavefronts without a border pixel skip the loop
     constexpr int KK = 2 * R + 1;
     unsigned my = 1u, mx = 1u;
 #pragma unroll
     for (int i = 1; i < KK; ++i) {
-      my |= (fo.y(i <= R ? -i : H - 1 + (i - R), H) == y ? 1u : 0u) << i;
-      mx |= (fo.x(i <= R ? -i : W - 1 + (i - R), W) == xx ? 1u : 0u) << i;
+      const int ry = i <= R ? -i : H - 1 + (i - R), rx = i <= R ? -i : W - 1 + (i - R);
+      const int vyu = ry - (bd.y0 - R);
+      my |= ((fo.y(ry, H) == ps.y && vyu >= 0 && vyu < bd.rows) ? 1u : 0u) << i;
+      mx |= (fo.x(rx, W) == ps.x ? 1u : 0u) << i;
     }
     unsigned mask = 0u;
 #pragma unroll
@@ -568,106 +544,40 @@ __global__ void __launch_bounds__(512) bwd_tile(const KP g, const TileGeo tg, co
       const int c = __builtin_ctz(mask);
       mask &= mask - 1u;
       const int iy = fdivi(c, KK), ix = c - iy * KK;
-      const int uy_ = iy == 0 ? y : (iy <= R ? -iy : H - 1 + (iy - R));
-      const int ux_ = ix == 0 ? xx : (ix <= R ? -ix : W - 1 + (ix - R));
-      {
-        // the N taps of this ring position at once: every LDS read first, then the sums
-        float2 qv[N];
-        float iq[N];
-        int jv[N];
+      const int uy = iy == 0 ? ps.y : (iy <= R ? -iy : H - 1 + (iy - R));
+      const int ux = ix == 0 ? ps.x : (ix <= R ? -ix : W - 1 + (ix - R));
+      const int sy = ps.y - uy, sx = ps.x - ux;                       // r - u: slot j of r is slot j + (sy, sx) of u
+      const float* wu = Wr + ((uy - (bd.y0 - R)) * Wu + ux + R) * K2 + sy * K + sx;
+      bool oky[K], okx[K];
 #pragma unroll
-        for (int n = 0; n < N; ++n) {
-          int dy, dx;
-          tap_offset<R>(n, dy, dx);
-          const int py = uy_ - dy, px = ux_ - dx, ry = py - y, rx = px - xx;
-          const bool ok = py >= 0 && py < H && px >= 0 && px < W && ry >= -R && ry <= R && rx >= -R && rx <= R && py >= ya && py < yb;
-          const int idx = ok ? n * npA + (py - ya) * W + px : 0;
-          jv[n] = ok ? (ry + R) * K + rx + R : -1;
-          if (M == NFP_COSINE) {
-            qv[n] = AD[idx];
-            iq[n] = ipn[ok ? (py - bd.y0 + R) * Wu + px + R : 0];
-          } else {
-            qv[n] = make_float2(CC[idx], 0.f);
-            iq[n] = 0.f;
-          }
-        }
-#pragma unroll
-        for (int n = 0; n < N; ++n) {
-          const bool ok = jv[n] >= 0;
-          float add;
-          if (M == NFP_COSINE) {
-            add = ok ? crossw(ipr, iq[n]) * qv[n].x : 0.f;
-            Dsum += ok ? qv[n].y * diagw(ipr, iq[n]) : 0.f;
-          } else {
-            add = ok ? dneg * qv[n].x : 0.f;
-            Dsum += ok ? qv[n].x : 0.f;
-          }
-#pragma unroll
-          for (int j = 0; j < K2; ++j) wl[j] += j == jv[n] ? add : 0.f;
-        }
+      for (int d = 0; d < K; ++d) {
+        oky[d] = (unsigned)(d + sy) < (unsigned)K;
+        okx[d] = (unsigned)(d + sx) < (unsigned)K;
       }
-    }
-    // every LDS read of the pixel first, then the sums
-    float2 v1[N], v2[N];
-    float ipq[N];
-    bool inb[N];
-    bool iny[K], inx[K];
 #pragma unroll
-    for (int d = 0; d < K; ++d) {
-      iny[d] = y + d - R >= 0 && y + d - R < H;
-      inx[d] = xx + d - R >= 0 && xx + d - R < W;
-    }
-#pragma unroll
-    for (int n = 0; n < N; ++n) {
-      const int j = n < K2 / 2 ? n : n + 1, dy = j / K - R, dx = j % K - R, opp = N - 1 - n;
-      inb[n] = iny[dy + R] && inx[dx + R];
-      const int i1 = n * npA + lpA, i2 = inb[n] ? opp * npA + lpA + dy * W + dx : i1;
-      if (M == NFP_COSINE) {
-        v1[n] = AD[i1];
-        v2[n] = AD[i2];
-        ipq[n] = ipn[pv + dy * Wu + dx];
-      } else {
-        v1[n] = make_float2(CC[i1], 0.f);
-        v2[n] = make_float2(CC[i2], 0.f);
-        ipq[n] = 0.f;
+      for (int j = 0; j < K2; ++j) {
+        // (u's own centre is not a position of r's window: the copy's pull on itself is the pixel's own — below)
+        const bool ok = oky[j / K] && okx[j % K] && !(j / K + sy == R && j % K + sx == R);
+        const float val = wu[j];
+        w[j] += ok ? val : 0.f;
       }
+      w[K2 / 2] += wu[K2 / 2 - sy * K - sx];
     }
-#pragma unroll
-    for (int n = 0; n < N; ++n) {
-      const int j = n < K2 / 2 ? n : n + 1;
-      if (M == NFP_COSINE) {
-        const float S = v1[n].x + (inb[n] ? v2[n].x : 0.f);
-        Dsum += (v1[n].y + (inb[n] ? v2[n].y : 0.f)) * diagw(ipr, ipq[n]);
-        w[j] = fmaf(crossw(ipr, ipq[n]), S, wl[j]);
-      } else {
-        const float c1 = v1[n].x, c2 = inb[n] ? v2[n].x : 0.f;
-        w[j] = fmaf(dneg, c1 + c2, wl[j]);
-        Dsum += fmaf(-dneg, c1, c2);  // 'Norm' quirk (nfp.py:74 vs 85): only the pair's NEIGHBOUR is pulled
-      }
-    }
-    w[K2 / 2] = fmaf(M == NFP_COSINE ? dfn[lp] : 1.f, Dsum, wl[K2 / 2]);
-  } else {
-#pragma unroll
-    for (int j = 0; j < K2; ++j) w[j] = 0.f;
   }
-  NFP_STAMP(9);
-  __syncthreads();  // the pair values are dead: their LDS becomes the x slab
-  NFP_STAMP(3);
 
   // ---- B: one pass over the channel block ---------------------------------------------------------------------------
-  int off[K2];
-#pragma unroll
-  for (int j = 0; j < K2; ++j) off[j] = swz(pos + (j / K - R) * Wp + (j % K - R)) - sp;
+  const int p = ps.y * W + ps.x;
   for (int c0 = cb0; c0 < cb1; c0 += g.Cc) {
     const int ncq = min(g.Cc, cb1 - c0) >> 2;
-    if (c0 > cb0) __syncthreads();  // previous chunk fully consumed
-    st.commit(slab);
-    __syncthreads();
-    if (c0 == cb0) NFP_STAMP(4);
-    if (c0 + g.Cc < cb1) st.issue(g, fo, bd, xb, Ppb, c0 + g.Cc, min(g.Cc, cb1 - c0 - g.Cc) >> 2, t, T);
-    if (active) {
-      for (int cq = gl; cq < ncq; cq += g.G) {
-        const float4* row = slab + cq * Ppb + sp;
+    if (c0 > cb0) {
+      __syncthreads();  // previous chunk fully consumed
+      st.commit(slab, ps, G, Ppb, ncq, dump);
+      __syncthreads();
+    }
+    if (c0 + g.Cc < cb1) st.issue(g, ps, xb, G, c0 + g.Cc, min(g.Cc, cb1 - c0 - g.Cc) >> 2);
+    if (ps.own) {
+      for (int cq = ps.gl; cq < ncq; cq += G) {
+        const float4* rc = slab + cq * Ppb + v - R;
         float4 r4 = make_float4(0.f, 0.f, 0.f, 0.f);
         if constexpr (POOL) {
           const float4 gg = *(const float4*)(ggap + (long long)b * g.C + c0 + 4 * cq);
@@ -675,7 +585,7 @@ __global__ void __launch_bounds__(512) bwd_tile(const KP g, const TileGeo tg, co
         }
 #pragma unroll
         for (int j = 0; j < K2; ++j) {
-          const float4 q = row[off[j]];
+          const float4 q = (rc + (j / K - R) * Wu)[j % K];
           r4.x = fmaf(w[j], q.x, r4.x);
           r4.y = fmaf(w[j], q.y, r4.y);
           r4.z = fmaf(w[j], q.z, r4.z);

@@ -12,15 +12,21 @@ namespace {
 #ifndef NFP_TILE_WGS
 #define NFP_TILE_WGS 512
 #endif
+#ifndef NFP_TILE_THREADS
+#define NFP_TILE_THREADS 480   // threads per workgroup the band height aims at
+#endif
 #ifndef NFP_TILE_LDS_KB
 #define NFP_TILE_LDS_KB 78     // per workgroup, so that two share a compute unit
 #endif
+int tile_wgs() { return g_sw.tile_wgs > 0 ? (int)g_sw.tile_wgs : NFP_TILE_WGS; }
+size_t tile_lds() { return (size_t)(g_sw.tile_lds_kb > 0 ? (int)g_sw.tile_lds_kb : NFP_TILE_LDS_KB) * 1024; }
+int tile_cap(int dflt) { return g_sw.tile_cap > 0 ? std::min((int)g_sw.tile_cap, 1024) : dflt; }
 bool tile_geometry(const KP& g) {
   if (g.stride != 1 || g.dil != 1 || g.pad != g.R || g.mode == NFP_PAD_CIRCULAR || g.rs == 12) return false;
   if (g.R != 1 && g.R != 2) return false;
-  // a band of one row must fit the forward's threads
-  if (g.W < 4 || g.W < 2 * g.R + 2 || (g.W + 2 * g.R) * (1 + 2 * g.R) > 1024) return false;
-  return g.W <= 512;                                                        // ... and the backward's
+  // one thread per padded position: the smallest band (R + 1 rows and its halo) must fit a workgroup
+  if (g.W < 2 * g.R + 2 || g.H < g.R + 1) return false;
+  return (g.W + 2 * g.R) * (3 * g.R + 1) <= 1024;
 }
 }  // namespace
 
@@ -30,7 +36,8 @@ bool tile_ok(const KP& g, const void* x, const void* gx) {
   const bool nhwc = g.sC == 1 && g.sW == g.C && g.sH == (long long)g.W * g.C;
   if (!g.contig && !nhwc) return false;
   const int es = g.dtype == NFP_F32 ? 4 : 2;
-  if ((long long)g.C * g.P * es >= 0x7ffffff0LL) return false;             // 32-bit buffer offsets inside an image
+  // 32-bit buffer offsets inside an image, and room for the "reads zero" offset (nfp_tile.h::Oob)
+  if ((long long)std::max(g.C, g.N) * g.P * es >= 0x7ffffff0LL) return false;
   if (!g.contig) {
     const uintptr_t m = g.dtype == NFP_F32 ? 15 : 7;
     if (((uintptr_t)x & m) || ((uintptr_t)gx & m) || ((g.sB * es) & m) || ((g.gB * es) & m)) return false;
@@ -40,46 +47,65 @@ bool tile_ok(const KP& g, const void* x, const void* gx) {
 
 namespace {
 
+// Bands.  Every band re-reads and re-sums its 2R halo rows, so rows per band >= 6R keeps that at a third; beyond that,
+// SMALLER workgroups win (one thread per padded position: ~480 threads, three or four workgroups per compute unit
+// overlapping each other's load / sum / store phases) — measured on the MultiStage maps at B = 256
+// (profiles/r03_v_tile_launch_constants.jsonl): 112x112 best at 6 rows (912 threads), 56x56 at 6 (464), 28x28 at 14 (480).
+// At least tile_wgs() workgroups on the chip; every band at least R + 1 rows (the ring rows a border pixel collects
+// from lie in its own band's halo).  Returns the rows of the largest band, or 0.
+int tile_bands(const KP& g, int rb_cap, int& nb) {
+  if (rb_cap < std::min(g.H, g.R + 1)) return 0;
+  const int nb_max = std::max(1, g.H / (g.R + 1));
+  nb = std::max(ceil_div(g.H, rb_cap), std::min(nb_max, ceil_div(tile_wgs(), g.B)));
+  if (nb > nb_max) return 0;
+  return ceil_div(g.H, nb);
+}
+int tile_rows_wanted(const KP& g, int cap) {
+  const int Wu = g.W + 2 * g.R;
+  const int want = std::max(6 * g.R, NFP_TILE_THREADS / Wu - 2 * g.R);
+  return std::max(1, std::min(std::min(g.H, cap / Wu - 2 * g.R), want));
+}
+// channel groups per position: one, unless the chip would be short of threads (small batches)
+int tile_groups(const KP& g, int nb, int npu, int cap, int cq) {
+  int lg = 0;
+  while (lg < 5 && (2 << lg) * npu <= cap && (2 << lg) <= cq && (long long)g.B * nb * npu * (1 << lg) < 256LL * 1024) ++lg;
+  return lg;
+}
+
 template <int R, int M, bool BF, bool NHWC, bool POOL = false>
 int launch_fwd_tile_t(KP g, const void* x, void* out, float* saved, hipStream_t st, float* part = nullptr, int* nb_out = nullptr) {
   constexpr int NF = Win<R>::NF, N = Win<R>::N;
-  const int Wp = nfp::tile_row_stride(g.W, R), Wu = g.W + 2 * R;
+  const int Wu = g.W + 2 * R;
   for (int attempt = 0; attempt < 2; ++attempt) {
-    // first choice: two workgroups per compute unit — half of LDS each; k = 3 runs in 64 registers (up to 1024 threads),
-    // k = 5 in up to 128 (at most 512 threads).  Second: one workgroup of up to 1024 threads and all of LDS.
-    const size_t budget = attempt == 0 ? (size_t)NFP_TILE_LDS_KB * 1024 : (size_t)kLdsMax;
-    const int kCap = (R == 1 || attempt == 1) ? 1024 : 512;   // threads per workgroup
-    const int rb_max = std::min(g.H, kCap / Wu - 2 * R);
-    for (int rb0 = rb_max; rb0 >= 1; --rb0) {
-      int nb = std::max(ceil_div(g.H, rb0), std::min(g.H, ceil_div(NFP_TILE_WGS, g.B)));
-      const int rb = ceil_div(g.H, nb);
-      nb = ceil_div(g.H, rb);
-      const int rows = rb + 2 * R, npos = rows * Wp, npu = rows * Wu, nbp = rb * g.W;
-      int lg = 0;
-      while (lg < 5 && (2 << lg) * npu <= kCap && (2 << lg) <= g.C / 4) ++lg;
-      const int G = 1 << lg, T = ((G * npu + 63) / 64) * 64;
-      const int ppb = nfp::band_row_slots(npos, lg);
-      const size_t tail = (size_t)(NF + 1) * npu * 4 + (POOL ? (size_t)N * nbp * 4 : 0);
+    // first choice: two workgroups of up to 1024 threads per compute unit — half of LDS each, 64 registers.
+    // Second: one workgroup and all of LDS.
+    const size_t budget = attempt == 0 ? tile_lds() : (size_t)kLdsMax;
+    const int kCap = tile_cap(1024);                           // threads per workgroup (64 registers either radius)
+    for (int rb0 = tile_rows_wanted(g, kCap); rb0 >= 1; --rb0) {
+      int nb = 1;
+      const int rb = tile_bands(g, rb0, nb);
+      if (rb < 1) break;
+      const int rows = rb + 2 * R, npu = rows * Wu, nbp = rb * g.W;
+      const int lg = tile_groups(g, nb, npu, kCap, g.C / 4), G = 1 << lg;
+      const int ppb = nfp::band_row_slots((npu + 3) & ~3, lg);
+      const size_t tail = 16 + (size_t)(NF + 1) * npu * 4 + (POOL ? (size_t)N * nbp * 4 : 0);
       if (tail + (size_t)ppb * 16 > budget) continue;
       int ncq = (int)((budget - tail) / ((size_t)ppb * 16));
-      if (NHWC) {
-        ncq = std::min(ncq, nfp::kFwdKN * T / npu);
-      } else {
-        ncq = std::min(ncq, nfp::kFwdKB * T / (rows * ((g.W + 3) / 4)));
-        ncq = std::min(ncq, nfp::kFwdKR * T / (rows * 2 * R));
-      }
+      ncq = std::min(ncq, std::min(nfp::kTileKQ * G, g.C / 4));
       if (ncq < 1) continue;
       const int total = g.C / 4, nch = ceil_div(total, ncq);
       g.Cc = 4 * ceil_div(total, nch);
       g.G = G;
-      g.Tc = lg;
       const size_t lds = (size_t)(g.Cc / 4) * ppb * 16 + tail;
-      nfp::TileGeo tg = {rb, nb, Wp, 1};
+      nfp::TileGeo tg = {nb, rows, Wu, ppb, 1};
       if (nb_out) *nb_out = nb;
       snprintf(g_variant, sizeof(g_variant), "fwd_tile<R%d,%s,%s,%s%s>x%d", R, hot_name(g), BF ? "bf16" : "f32",
                NHWC ? "nhwc" : "nchw", POOL ? ",pool" : "", nb);
-      return launch("fwd_tile", fwd_tile<R, M, BF, NHWC, POOL>, dim3((unsigned)(g.B * nb)), dim3(T), lds, st, g, tg, x, out, saved,
-                    part);
+      const dim3 grid((unsigned)(g.B * nb)), block(G, Wu, rows);
+      if constexpr (M == NFP_COSINE) {
+        if (g.gfc) return launch("fwd_tile", fwd_tile<R, M, BF, NHWC, POOL, true>, grid, block, lds, st, g, tg, x, out, saved, part);
+      }
+      return launch("fwd_tile", fwd_tile<R, M, BF, NHWC, POOL, false>, grid, block, lds, st, g, tg, x, out, saved, part);
     }
   }
   return kNotApplicable;
@@ -88,51 +114,47 @@ int launch_fwd_tile_t(KP g, const void* x, void* out, float* saved, hipStream_t 
 template <int R, int M, bool BF, bool NHWC, bool POOL = false>
 int launch_bwd_tile_t(KP g, const void* x, const void* go, const void* out, const float* saved, void* gx, hipStream_t st,
                       const float* ggap = nullptr, const float* gnfpm = nullptr) {
-  constexpr int N = Win<R>::N;
-  const int Wp = nfp::tile_row_stride(g.W, R), Wu = g.W + 2 * R, pvw = M == NFP_COSINE ? 2 : 1;
-  const int rb_max = std::min(g.H, 512 / g.W);
-  if (rb_max < 1) return kNotApplicable;
+  constexpr int N = Win<R>::N, K2 = Win<R>::K2;
+  const int Wu = g.W + 2 * R;
   for (int attempt = 0; attempt < 2; ++attempt) {
-    const size_t budget = attempt == 0 ? (size_t)NFP_TILE_LDS_KB * 1024 : (size_t)kLdsMax;
-    for (int rb0 = rb_max; rb0 >= 1; --rb0) {
-      int nb = std::max(ceil_div(g.H, rb0), std::min(g.H, ceil_div(NFP_TILE_WGS, g.B)));
-      const int rb = ceil_div(g.H, nb);
-      nb = ceil_div(g.H, rb);
-      const int rows = rb + 2 * R, npos = rows * Wp, npu = rows * Wu, nbp = rb * g.W, npA = std::min(g.H, rows) * g.W;
-      const size_t fixed = ((size_t)(npu + nbp) * 4 + 15) & ~(size_t)15;   // ipn, dfn (the window weights live in registers)
-      const size_t pv = (size_t)N * npA * pvw * 4;
-      const int ppb = npos | 1;
-      if (fixed + std::max(pv, (size_t)ppb * 16) > budget) continue;
+    // first choice: two workgroups per compute unit (k = 3: 64 registers, up to 1024 threads each; k = 5: 128, up to 512)
+    const size_t budget = attempt == 0 ? tile_lds() : (size_t)kLdsMax;
+    const int kCap = tile_cap((R == 1 || attempt == 1) ? 1024 : 512);
+    for (int rb0 = tile_rows_wanted(g, kCap); rb0 >= 1; --rb0) {
+      int nb = 1;
+      const int rb = tile_bands(g, rb0, nb);
+      if (rb < 1) break;
+      const int rows = rb + 2 * R, npu = rows * Wu, PL = (rows + 2 * R) * Wu;
+      const size_t fixed = (size_t)((PL + 3) & ~3) * 4;                       // ipn
+      const size_t pv = (size_t)N * PL * 4;                                   // pair values, every plane with its zero rows
+      const size_t wr = 16 + (size_t)(npu * K2 + 4 * K2) * 4;                 // spare slot, ring rows (+ slack)
+      if (fixed + pv > budget) continue;
       // channel blocks: enough workgroups to fill the chip when images x bands do not
-      int S = ceil_div(NFP_TILE_WGS, g.B * nb);
+      int S = ceil_div(tile_wgs(), g.B * nb);
       if (S > g.C / 4) S = g.C / 4;
       if (S < 1) S = 1;
       g.Cwg = round4(ceil_div(g.C, S));
       S = ceil_div(g.C, g.Cwg);
-      g.G = std::max(1, std::min(512 / nbp, g.Cwg / 4));
-      const int T = ((nbp * g.G + 63) / 64) * 64;
-      int ncq = (int)((budget - fixed) / ((size_t)ppb * 16));
-      if (NHWC) {
-        ncq = std::min(ncq, nfp::kBwdKN * T / npu);
-      } else {
-        ncq = std::min(ncq, nfp::kBwdKB * T / (rows * ((g.W + 3) / 4)));
-        ncq = std::min(ncq, nfp::kBwdKR * T / (rows * 2 * R));
-      }
+      const int lg = tile_groups(g, nb * S, npu, kCap, g.Cwg / 4), G = 1 << lg;
+      const int ppb = nfp::band_row_slots((npu + 3) & ~3, lg);
+      if (fixed + wr + (size_t)ppb * 16 > budget) continue;
+      int ncq = (int)((budget - fixed - wr) / ((size_t)ppb * 16));
+      ncq = std::min(ncq, std::min(nfp::kTileKQ * G, g.Cwg / 4));
       if (ncq < 1) continue;
       const int total = g.Cwg / 4, nch = ceil_div(total, ncq);
       g.Cc = 4 * ceil_div(total, nch);
-      g.G = even_groups(g.Cc / 4, g.G);
-      const size_t lds = fixed + std::max(pv, (size_t)(g.Cc / 4) * ppb * 16);
-      nfp::TileGeo tg = {rb, nb, Wp, S};
+      g.G = G;
+      const size_t lds = fixed + std::max(pv, (size_t)(g.Cc / 4) * ppb * 16 + wr);
+      nfp::TileGeo tg = {nb, rows, Wu, ppb, S};
       snprintf(g_variant, sizeof(g_variant), "bwd_tile<R%d,%s,%s,%s%s>x%d", R, hot_name(g), BF ? "bf16" : "f32",
                NHWC ? "nhwc" : "nchw", POOL ? ",pool" : "", nb);
+      const dim3 grid((unsigned)(g.B * nb * S)), block(G, Wu, rows);
       if constexpr (M == NFP_COSINE) {
         if (g.gfc)
-          return launch("bwd_tile", bwd_tile<R, M, BF, NHWC, POOL, true>, dim3((unsigned)(g.B * nb * S)), dim3(T), lds, st, g, tg, x, go,
-                        out, saved, gx, ggap, gnfpm);
+          return launch("bwd_tile", bwd_tile<R, M, BF, NHWC, POOL, true>, grid, block, lds, st, g, tg, x, go, out, saved, gx, ggap,
+                        gnfpm);
       }
-      return launch("bwd_tile", bwd_tile<R, M, BF, NHWC, POOL>, dim3((unsigned)(g.B * nb * S)), dim3(T), lds, st, g, tg, x, go, out,
-                    saved, gx, ggap, gnfpm);
+      return launch("bwd_tile", bwd_tile<R, M, BF, NHWC, POOL>, grid, block, lds, st, g, tg, x, go, out, saved, gx, ggap, gnfpm);
     }
   }
   return kNotApplicable;

@@ -6,7 +6,10 @@ sys.path.insert(0, os.getcwd())
 import torch
 from neighbour_feature_pooling_amd import NFPPooling
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-for C, S in ((16, 112), (24, 56), (40, 28), (128, 28), (64, 56)):
+SHAPES = ((16, 112), (24, 56), (40, 28), (128, 28), (64, 56))
+if len(sys.argv) > 3:          # one shape only: run_bigmaps_for_rocprof.py B C S
+    SHAPES = ((int(sys.argv[2]), int(sys.argv[3])),)
+for C, S in SHAPES:
     m = NFPPooling(C, R=1, measure="cosine", padding=1)
     xs = [torch.randn(B, C, S, S, device="cuda", requires_grad=True) for _ in range(3)]
     go = torch.randn(B, 8, S, S, device="cuda")

@@ -8,6 +8,19 @@ import torch
 from neighbour_feature_pooling_amd import NFPPooling, _abi
 from bench import time_kernel_graph, algorithmic_bytes
 L = _abi.load()
+
+
+def warm(fn, ms=40.0):
+    """clocks and caches: run `fn` for ~ms before anything is timed (the first configuration measured after an idle
+    moment otherwise reads 10-20 % slow)"""
+    import time
+    t = time.perf_counter()
+    while (time.perf_counter() - t) * 1e3 < ms:
+        for _ in range(20):
+            fn()
+        torch.cuda.synchronize()
+
+
 s = torch.cuda.Stream()
 out_f = open(sys.argv[1], "w") if len(sys.argv) > 1 else None
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 256
@@ -26,6 +39,7 @@ for C, S in shapes:
             torch.autograd.grad(o, x, go, retain_graph=True)
             torch.cuda.synchronize()
             bv = L.nfp_last_variant().decode()
+            warm(lambda: m(x))
             tf = time_kernel_graph(lambda: m(x), 10, s)
             tb = time_kernel_graph(lambda: torch.autograd.grad(o, x, go, retain_graph=True), 10, s)
         fb, bb = algorithmic_bytes(B, C, S * S, 8, 4)
