@@ -68,7 +68,7 @@ int tile_rows_wanted(const KP& g, int cap) {
 // channel groups per position: one, unless the chip would be short of threads (small batches)
 int tile_groups(const KP& g, int nb, int npu, int cap, int cq) {
   int lg = 0;
-  while (lg < 5 && (2 << lg) * npu <= cap && (2 << lg) <= cq && (long long)g.B * nb * npu * (1 << lg) < 256LL * 1024) ++lg;
+  while (lg < 5 && (2 << lg) * npu <= cap && (2 << lg) <= cq && (long long)g.B * nb * npu * (1 << lg) < 128LL * 1024) ++lg;
   return lg;
 }
 
@@ -96,6 +96,11 @@ int launch_fwd_tile_t(KP g, const void* x, void* out, float* saved, hipStream_t 
       const int total = g.C / 4, nch = ceil_div(total, ncq);
       g.Cc = 4 * ceil_div(total, nch);
       g.G = G;
+      g.Tc = -1;
+      if (NHWC && G == 1) {   // wavefront-shared staging: chunks of 1, 2 or 4 quads (nfp_tile.h::TileStage)
+        g.Tc = ncq >= 4 ? 2 : (ncq >= 2 ? 1 : 0);
+        g.Cc = 4 << g.Tc;
+      }
       const size_t lds = (size_t)(g.Cc / 4) * ppb * 16 + tail;
       nfp::TileGeo tg = {nb, rows, Wu, ppb, 1};
       if (nb_out) *nb_out = nb;
@@ -144,6 +149,11 @@ int launch_bwd_tile_t(KP g, const void* x, const void* go, const void* out, cons
       const int total = g.Cwg / 4, nch = ceil_div(total, ncq);
       g.Cc = 4 * ceil_div(total, nch);
       g.G = G;
+      g.Tc = -1;
+      if (NHWC && G == 1) {
+        g.Tc = ncq >= 4 ? 2 : (ncq >= 2 ? 1 : 0);
+        g.Cc = 4 << g.Tc;
+      }
       const size_t lds = fixed + std::max(pv, (size_t)(g.Cc / 4) * ppb * 16 + wr);
       nfp::TileGeo tg = {nb, rows, Wu, ppb, S};
       snprintf(g_variant, sizeof(g_variant), "bwd_tile<R%d,%s,%s,%s%s>x%d", R, hot_name(g), BF ? "bf16" : "f32",

@@ -28,8 +28,7 @@ B = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 layout = sys.argv[3] if len(sys.argv) > 3 else "nchw"
 shapes = [(16, 112), (24, 56), (40, 28), (128, 28), (64, 56)]
 settings = [dict(NFP_TILE_WGS=w, NFP_TILE_LDS_KB=l, NFP_TILE_CAP=c) for w, l, c in
-            [(512, 78, 1024), (512, 78, 1024), (512, 78, 768), (1024, 78, 768), (512, 52, 640), (1024, 52, 640), (512, 78, 512),
-             (1024, 78, 512), (1024, 52, 512), (1024, 38, 512), (1536, 38, 384), (1536, 38, 320), (2048, 38, 256)]]
+            [(512, 78, 1024), (512, 78, 1024), (512, 52, 1024), (512, 38, 1024), (512, 160, 1024), (1024, 78, 1024)]]
 for C, S in shapes:
     m = NFPPooling(C, R=1, measure="cosine", padding=1)
     x = torch.randn(B, C, S, S, device="cuda")
