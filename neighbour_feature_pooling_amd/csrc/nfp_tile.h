@@ -128,15 +128,45 @@ struct TilePos {
 
 // The thread's own position of a channel chunk: quads gl, gl + G, ... (the quads it will sum), every load issued back
 // to back into registers, written to LDS later so that arithmetic can run under their latency.
-// Channels-last with one thread per position (g.Tc >= 0): a lane reading 16 bytes of ITS pixel makes every load
-// instruction touch 64 cache lines for 1 KB — four times the L1 time of the same bytes read densely
-// ([256,64,56,56] forward 58 us against 37 us for NCHW).  Instead the 64 lanes of a wavefront share the chunk of the
-// wavefront's 64 positions: lane = (position % (64 / Q), quad) with Q = 2^Tc quads per chunk, so Q adjacent lanes read
-// 16 Q contiguous bytes; the pixel offset of somebody else's position comes through ds_bpermute.
-template <int R, bool BF, bool NHWC>
+// Channels-last, one thread per position (g.Tc >= 0): a lane reading 16 bytes of ITS pixel makes every load instruction touch
+// 64 cache lines for 1 KB — four times the L1 time of the same bytes read densely ([256,64,56,56] forward 58 us against
+// 37 us for NCHW).  Instead the lanes of a wavefront share the chunk of the wavefront's positions: Q = 2^Tc quads per
+// chunk, Q adjacent lanes read 16 Q contiguous bytes; the pixel offset of somebody else's position comes through
+// ds_bpermute.  (A workgroup's partial last wavefront keeps the one-lane-one-pixel form — a wave-uniform choice.)
+// CST (bwd_tile's variant that also STORES grad_x that way, phase B) needs every lane of every wavefront in the scheme:
+// CoopMap deals items i = lane + k * n over the n lanes a wavefront has.
+struct CoopMap {   // the wavefront's share of a chunk, as seen by one lane
+  int lq, wb, n;   // log2 Q; the wavefront's first position; its lanes
+  int lane;
+  __device__ __forceinline__ CoopMap(const KP& g, int v, int npu) {
+    lq = g.Tc;
+    lane = __lane_id();
+    wb = v - lane;
+    n = min(64, npu - wb);
+  }
+  __device__ __forceinline__ void item(int k, int& psub, int& cq) const {
+    const int i = lane + k * n;
+    psub = i >> lq;
+    cq = i & ((1 << lq) - 1);
+  }
+};
+template <int R, bool BF, bool NHWC, bool CST>
 struct TileStage {
   float4 q[kTileKQ];
   __device__ __forceinline__ void issue(const KP& g, const TilePos<R>& ps, Rsrc xb, int G, int c0, int ncq, int npu) {
+    if constexpr (CST) {
+      const CoopMap cm(g, ps.v, npu);
+      const int eb = (ps.src * g.C) | ps.template zoff<BF>();
+#pragma unroll
+      for (int k = 0; k < kTileKQ; ++k) {
+        int psub, cq;
+        cm.item(k, psub, cq);
+        const int e = __builtin_amdgcn_ds_bpermute(psub << 2, eb) + 4 * cq;
+        const bool ok = k < (1 << cm.lq) && cq < ncq;
+        q[k] = load_px4<BF>(xb, ok ? e : Oob<BF>::e, c0);
+      }
+      return;
+    }
     if constexpr (NHWC) {
       // (a workgroup's last wavefront may be partial: it keeps the one-lane-one-pixel form — a wave-uniform choice)
       if (g.Tc >= 0 && ps.v - (int)__lane_id() + 64 <= npu) {
@@ -164,10 +194,21 @@ struct TileStage {
         q[k] = make_float4(load_1<BF>(xb, e, 0), load_1<BF>(xb, e, g.P), load_1<BF>(xb, e, 2 * g.P), load_1<BF>(xb, e, 3 * g.P));
       }
     }
-  }
+    }
   // (a quad past the chunk's end goes to the spare slot `dump`: an address select; a predicated LDS store costs registers)
   __device__ __forceinline__ void commit(float4* slab, const KP& g, const TilePos<R>& ps, int G, int Ppb, int ncq, int dump,
                                          int npu) const {
+    if constexpr (CST) {
+      const CoopMap cm(g, ps.v, npu);
+#pragma unroll
+      for (int k = 0; k < kTileKQ; ++k) {
+        int psub, cq;
+        cm.item(k, psub, cq);
+        const bool ok = k < (1 << cm.lq) && cq < ncq;
+        slab[ok ? cq * Ppb + cm.wb + psub : dump] = q[k];
+      }
+      return;
+    }
     if constexpr (NHWC) {
       if (g.Tc >= 0 && ps.v - (int)__lane_id() + 64 <= npu) {
         const int lq = g.Tc, lane = __lane_id(), wb = ps.v - lane;
@@ -186,8 +227,18 @@ struct TileStage {
       const int cq = ps.gl + k * G;
       slab[cq < ncq ? cq * Ppb + ps.v : dump] = q[k];
     }
-  }
+    }
 };
+
+// Ring positions of a band, numbered compactly (the backward keeps a window row for each: 2R per padded row, and the 2R
+// ring rows above / below the image): padded row vy, image coordinates (y, x) of the position.
+template <int R>
+__device__ __forceinline__ int ring_slot(int vy, int y, int x, int rows, int W, int H) {
+  const bool col = x < 0 || x >= W;
+  const int cslot = vy * 2 * R + (x < 0 ? x + R : x - W + R);
+  const int rslot = rows * 2 * R + (y < 0 ? y + R : R + y - H) * W + x;
+  return col ? cslot : rslot;
+}
 
 // sum over the 64 lanes of a wavefront, valid in lane 63 (fixed DPP tree: group_sum covers each half, then the row
 // broadcast of lane 31 into the upper half)
@@ -225,7 +276,7 @@ __global__ void __launch_bounds__(1024, (R == 1 ? 8 : 4)) fwd_tile(const KP g, c
   NFP_STAMP_INIT();
   NFP_STAMP(0);
 
-  TileStage<R, BF, NHWC> st;
+  TileStage<R, BF, NHWC, false> st;
   st.issue(g, ps, xb, G, 0, min(g.Cc, g.C) >> 2, npu);
   __builtin_amdgcn_sched_barrier(0);
 
@@ -415,12 +466,13 @@ __global__ void __launch_bounds__(256) pool_fold(const float* __restrict__ part,
 // LDS (floats): ipn [PL] | pair values [N][PL] (cosine: sg = +-grad_out; L2: c = -+g / d) — PL = (rows + 2R) * Wu: R
 // rows of ZEROS above and below the band in every plane, so that a tap at a constant offset of ANY position reads a
 // value (a column past the row's end lands in the ring columns of the next row: zeros too).  After phase A the pair
-// values are dead: the x slab lies over them, and behind the slab the window rows of the ring positions [npu][K2].
+// values are dead: the x slab lies over them, and behind the slab the window rows of the ring positions
+// [rows * 2R + 2R * W][K2] (ring_slot).
 // (Cosine: the pair {r, r + d} has ONE similarity s, which reaches the backward twice — out[n][r] and
 // out[opp n][r + d], equal up to the forward's rounding; the pull of both on |x_r| uses r's own copy, so that only the
 // gradients travel through LDS.)
-template <int R, int M, bool BF, bool NHWC, bool POOL = false, bool GFC = false>
-__global__ void __launch_bounds__(1024, (R == 1 ? 8 : 4)) bwd_tile(const KP g, const TileGeo tg, const void* __restrict__ x,
+template <int R, int M, bool BF, bool NHWC, bool POOL = false, bool GFC = false, bool CST = false>
+__global__ void __launch_bounds__(1024, (R == 1 ? (CST ? 5 : 8) : 4)) bwd_tile(const KP g, const TileGeo tg, const void* __restrict__ x,
                                                 const void* __restrict__ go, const void* __restrict__ out,
                                                 const float* __restrict__ saved, void* __restrict__ gx,
                                                 const float* __restrict__ ggap, const float* __restrict__ gnfpm) {
@@ -453,7 +505,7 @@ __global__ void __launch_bounds__(1024, (R == 1 ? 8 : 4)) bwd_tile(const KP g, c
 
   // ---- A1: the position's own pairs (every tap), its norm factor; all loads first, then the x chunk ----------------
   // A position that owns no pairs (ring, outside the image, rows past the band) loads zeros: its pair values come out 0.
-  TileStage<R, BF, NHWC> st;
+  TileStage<R, BF, NHWC, CST> st;
   float w[K2], sv[N];
   float dfn = 0.f, ipr = 1.f;
   {
@@ -554,8 +606,9 @@ __global__ void __launch_bounds__(1024, (R == 1 ? 8 : 4)) bwd_tile(const KP g, c
   // A ring position is a copy of the image pixel it folds onto (reflect / replicate): its window row goes to LDS for
   // that pixel's thread
   if (ps.live && !ps.real && ps.gl == 0) {
+    float* wrow = Wr + ring_slot<R>(ps.vy, ps.y, ps.x, tg.rows, W, H) * K2;
 #pragma unroll
-    for (int j = 0; j < K2; ++j) Wr[v * K2 + j] = w[j];
+    for (int j = 0; j < K2; ++j) wrow[j] = w[j];
   }
   __syncthreads();
   NFP_STAMP(4);
@@ -582,7 +635,7 @@ __global__ void __launch_bounds__(1024, (R == 1 ? 8 : 4)) bwd_tile(const KP g, c
       const int uy = iy == 0 ? ps.y : (iy <= R ? -iy : H - 1 + (iy - R));
       const int ux = ix == 0 ? ps.x : (ix <= R ? -ix : W - 1 + (ix - R));
       const int sy = ps.y - uy, sx = ps.x - ux;                       // r - u: slot j of r is slot j + (sy, sx) of u
-      const float* wu = Wr + ((uy - (bd.y0 - R)) * Wu + ux + R) * K2 + sy * K + sx;
+      const float* wu = Wr + ring_slot<R>(uy - (bd.y0 - R), uy, ux, tg.rows, W, H) * K2 + sy * K + sx;
       bool oky[K], okx[K];
 #pragma unroll
       for (int d = 0; d < K; ++d) {
@@ -601,41 +654,85 @@ __global__ void __launch_bounds__(1024, (R == 1 ? 8 : 4)) bwd_tile(const KP g, c
   }
 
   // ---- B: one pass over the channel block ---------------------------------------------------------------------------
+  // CST (channels-last, one thread per position, pixels of 96 bytes and more): a lane storing 16 bytes of ITS pixel per
+  // quad leaves 64 scattered 16-byte writes per store instruction ([256,64,56,56]: the stores took 83 us of the kernel's
+  // 153, against 47 of 96 us in NCHW — profiles/r03_w_tile_backward_stores_ab.txt).  Instead a wavefront turns its
+  // results around in LDS — its own slots of the slab, once every wavefront has finished reading the chunk — and
+  // stores as it loaded: Q adjacent lanes write 16 Q contiguous bytes of one pixel.  Four results in registers: this
+  // variant is built for 96 registers (two workgroups of up to 640 threads per compute unit).
   const int p = ps.y * W + ps.x;
   for (int c0 = cb0; c0 < cb1; c0 += g.Cc) {
     const int ncq = min(g.Cc, cb1 - c0) >> 2;
     if (c0 > cb0) {
-      __syncthreads();  // previous chunk fully consumed
       st.commit(slab, g, ps, G, Ppb, ncq, dump, npu);
       __syncthreads();
     }
-    if (c0 + g.Cc < cb1) st.issue(g, ps, xb, G, c0 + g.Cc, min(g.Cc, cb1 - c0 - g.Cc) >> 2, npu);
-    if (ps.own) {
-      for (int cq = ps.gl; cq < ncq; cq += G) {
-        const float4* rc = slab + cq * Ppb + v - R;
-        float4 r4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if constexpr (POOL) {
-          const float4 gg = *(const float4*)(ggap + (long long)b * g.C + c0 + 4 * cq);
-          r4 = make_float4(gg.x * g.invP, gg.y * g.invP, gg.z * g.invP, gg.w * g.invP);
-        }
+    const bool more = c0 + g.Cc < cb1;
+    // (turning the results around takes 16 registers: there the next chunk is requested after the stores, not before the sums)
+    if (more && !CST) st.issue(g, ps, xb, G, c0 + g.Cc, min(g.Cc, cb1 - c0 - g.Cc) >> 2, npu);
+    auto one = [&](int cq) {
+      const float4* rc = slab + cq * Ppb + v - R;
+      float4 r4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if constexpr (POOL) {
+        const float4 gg = *(const float4*)(ggap + (long long)b * g.C + c0 + 4 * cq);
+        r4 = make_float4(gg.x * g.invP, gg.y * g.invP, gg.z * g.invP, gg.w * g.invP);
+      }
 #pragma unroll
-        for (int j = 0; j < K2; ++j) {
-          const float4 q = (rc + (j / K - R) * Wu)[j % K];
-          r4.x = fmaf(w[j], q.x, r4.x);
-          r4.y = fmaf(w[j], q.y, r4.y);
-          r4.z = fmaf(w[j], q.z, r4.z);
-          r4.w = fmaf(w[j], q.w, r4.w);
-        }
-        if constexpr (NHWC) {
-          store_px4<BF>(gxb, p * g.C + c0 + 4 * cq, 0, r4);
-        } else {
-          const int e = (c0 + 4 * cq) * P + p;
-          store_1<BF>(gxb, e, 0, r4.x);
-          store_1<BF>(gxb, e, P, r4.y);
-          store_1<BF>(gxb, e, 2 * P, r4.z);
-          store_1<BF>(gxb, e, 3 * P, r4.w);
+      for (int j = 0; j < K2; ++j) {
+        const float4 q = (rc + (j / K - R) * Wu)[j % K];
+        r4.x = fmaf(w[j], q.x, r4.x);
+        r4.y = fmaf(w[j], q.y, r4.y);
+        r4.z = fmaf(w[j], q.z, r4.z);
+        r4.w = fmaf(w[j], q.w, r4.w);
+      }
+      return r4;
+    };
+    if constexpr (CST) {
+      float4 rq[kTileKQ];
+#pragma unroll
+      for (int k = 0; k < kTileKQ; ++k) {
+        if (k < ncq) rq[k] = one(k);             // (wave-uniform bound; non-own positions compute something nobody stores)
+        __builtin_amdgcn_sched_barrier(0);        // (one quad after the other: interleaved, their 36 LDS reads want 144 registers)
+      }
+      __syncthreads();  // chunk fully consumed: a position's slots now carry its results to the lanes that store them
+#pragma unroll
+      for (int k = 0; k < kTileKQ; ++k)
+        if (k < ncq) slab[k * Ppb + v] = rq[k];
+      const CoopMap cm(g, v, npu);
+      const int pc = ps.own ? p * g.C : Oob<BF>::e;
+#pragma unroll
+      for (int k = 0; k < kTileKQ; ++k) {
+        int psub, cq;
+        cm.item(k, psub, cq);
+        if (k < (1 << cm.lq)) {
+          const float4 r4 = slab[min(cq, ncq - 1) * Ppb + cm.wb + psub];
+          const int e = __builtin_amdgcn_ds_bpermute(psub << 2, pc) + 4 * cq;
+#ifdef NFP_TILE_NOSTORE   // (diagnostic build only: what the kernel costs without its grad_x stores)
+          if (r4.x != 12345.678f) continue;
+#endif
+          store_px4<BF>(gxb, cq < ncq ? e : Oob<BF>::e, c0, r4);
         }
       }
+      if (more) st.issue(g, ps, xb, G, c0 + g.Cc, min(g.Cc, cb1 - c0 - g.Cc) >> 2, npu);
+    } else {
+      if (ps.own) {
+        for (int cq = ps.gl; cq < ncq; cq += G) {
+          const float4 r4 = one(cq);
+#ifdef NFP_TILE_NOSTORE
+          if (r4.x != 12345.678f) continue;
+#endif
+          if constexpr (NHWC) {
+            store_px4<BF>(gxb, p * g.C + c0 + 4 * cq, 0, r4);
+          } else {
+            const int e = (c0 + 4 * cq) * P + p;
+            store_1<BF>(gxb, e, 0, r4.x);
+            store_1<BF>(gxb, e, P, r4.y);
+            store_1<BF>(gxb, e, 2 * P, r4.z);
+            store_1<BF>(gxb, e, 3 * P, r4.w);
+          }
+        }
+      }
+      if (more) __syncthreads();  // chunk fully consumed
     }
     if (c0 == cb0) NFP_STAMP(5);
   }

@@ -3,6 +3,8 @@
 #include "nfp_launch.h"
 #include "nfp_tile.h"
 
+#include <type_traits>
+
 using namespace nfp;
 
 namespace nfp_host {
@@ -132,7 +134,7 @@ int launch_bwd_tile_t(KP g, const void* x, const void* go, const void* out, cons
       const int rows = rb + 2 * R, npu = rows * Wu, PL = (rows + 2 * R) * Wu;
       const size_t fixed = (size_t)((PL + 3) & ~3) * 4;                       // ipn
       const size_t pv = (size_t)N * PL * 4;                                   // pair values, every plane with its zero rows
-      const size_t wr = 16 + (size_t)(npu * K2 + 4 * K2) * 4;                 // spare slot, ring rows (+ slack)
+      const size_t wr = 16 + (size_t)((rows * 2 * R + 2 * R * g.W) * K2 + 4 * K2) * 4;   // spare slot, ring rows (+ slack)
       if (fixed + pv > budget) continue;
       // channel blocks: enough workgroups to fill the chip when images x bands do not
       int S = ceil_div(tile_wgs(), g.B * nb);
@@ -159,12 +161,29 @@ int launch_bwd_tile_t(KP g, const void* x, const void* go, const void* out, cons
       snprintf(g_variant, sizeof(g_variant), "bwd_tile<R%d,%s,%s,%s%s>x%d", R, hot_name(g), BF ? "bf16" : "f32",
                NHWC ? "nhwc" : "nchw", POOL ? ",pool" : "", nb);
       const dim3 grid((unsigned)(g.B * nb * S)), block(G, Wu, rows);
+      auto go_ = [&](auto gfc, auto cst) {
+        return launch("bwd_tile", bwd_tile<R, M, BF, NHWC, POOL, decltype(gfc)::value, decltype(cst)::value>, grid, block, lds, st, g,
+                      tg, x, go, out, saved, gx, ggap, gnfpm);
+      };
+      // dense grad_x stores through LDS (nfp_tile.h, phase B): channels-last with one thread per position, pixels of 256
+      // bytes and more (below, the scattered 16-byte stores of a pixel complete their cache lines soon enough: measured
+      // at 96 / 160 bytes, profiles/r03_w_tile_backward_stores_ab.txt), workgroups of up to 640 threads (the variant
+      // takes 96 registers: two such workgroups per compute unit)
+      const bool cst = NHWC && G == 1 && g.C * (BF ? 2 : 4) >= 256 && npu <= 640;
+      const std::true_type T_;
+      const std::false_type F_;
       if constexpr (M == NFP_COSINE) {
-        if (g.gfc)
-          return launch("bwd_tile", bwd_tile<R, M, BF, NHWC, POOL, true>, grid, block, lds, st, g, tg, x, go, out, saved, gx, ggap,
-                        gnfpm);
+        if (g.gfc) {
+          if constexpr (NHWC) {
+            if (cst) return go_(T_, T_);
+          }
+          return go_(T_, F_);
+        }
       }
-      return launch("bwd_tile", bwd_tile<R, M, BF, NHWC, POOL>, grid, block, lds, st, g, tg, x, go, out, saved, gx, ggap, gnfpm);
+      if constexpr (NHWC) {
+        if (cst) return go_(F_, T_);
+      }
+      return go_(F_, F_);
     }
   }
   return kNotApplicable;
