@@ -27,6 +27,18 @@ if [ -f neighbour_feature_pooling_amd/ab/manifest.json ]; then
   done > gpurun_out/r03_ab_round2_vs_round3.txt
   cat gpurun_out/r03_ab_round2_vs_round3.txt
 fi
-timeout -k 10 200 python scripts/sweep_bigmaps.py gpurun_out/r03_bigmaps_final.jsonl > gpurun_out/r03_bigmaps_final.log 2>&1; echo "bigmaps sweep rc=$?"
+timeout -k 10 400 python scripts/sweep_bigmaps.py gpurun_out/r03_bigmaps_final.jsonl > gpurun_out/r03_bigmaps_final.log 2>&1; echo "bigmaps sweep rc=$?"
 timeout -k 10 200 python scripts/sweep.py > gpurun_out/r03_shape_sweep.jsonl 2>&1; echo "shape sweep rc=$?"
 timeout -k 10 200 python scripts/gpu_fused_callers.py > gpurun_out/r03_fused_callers.jsonl 2>&1; echo "fused callers rc=$?"
+# ---- the rewritten row-band kernels (one thread per padded position) ---------------------------------------------------
+bash scripts/gpu_pmc_tile.sh 16 112 > gpurun_out/pmc_tile_after.log 2>&1; echo "tile pmc rc=$?"
+# grad_x stores of the row-band backward: the product, the same without its stores, and round 2's any-geometry kernels
+if [ -f neighbour_feature_pooling_amd/ab/manifest.json ]; then
+  for shp in 256,64,56,1,cosine 256,64,56,1,cosine,nhwc 256,40,28,1,cosine 256,40,28,1,cosine,nhwc 256,16,112,1,cosine; do
+    echo "== $shp"; AB_SHAPE=$shp timeout -k 10 300 python scripts/ab_flags.py --run 2>&1 | grep "fwd" | cut -c1-170
+  done > gpurun_out/r03_tile_backward_stores_ab.txt
+  cat gpurun_out/r03_tile_backward_stores_ab.txt
+fi
+timeout -k 10 400 python scripts/tile_vs_table_kernels.py gpurun_out/r03_tile_vs_table.jsonl > gpurun_out/r03_tile_vs_table.log 2>&1; echo "tile vs table rc=$?"
+bash scripts/gpu_multistage_step.sh > gpurun_out/r03_multistage.log 2>&1; echo "multistage rc=$?"
+bash scripts/gpu_train_steps.sh > gpurun_out/r03_train.log 2>&1; echo "train steps rc=$?"
