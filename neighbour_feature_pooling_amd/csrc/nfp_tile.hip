@@ -158,8 +158,6 @@ int launch_bwd_tile_t(KP g, const void* x, const void* go, const void* out, cons
       }
       const size_t lds = fixed + std::max(pv, (size_t)(g.Cc / 4) * ppb * 16 + wr);
       nfp::TileGeo tg = {nb, rows, Wu, ppb, S};
-      snprintf(g_variant, sizeof(g_variant), "bwd_tile<R%d,%s,%s,%s%s>x%d", R, hot_name(g), BF ? "bf16" : "f32",
-               NHWC ? "nhwc" : "nchw", POOL ? ",pool" : "", nb);
       const dim3 grid((unsigned)(g.B * nb * S)), block(G, Wu, rows);
       auto go_ = [&](auto gfc, auto cst) {
         return launch("bwd_tile", bwd_tile<R, M, BF, NHWC, POOL, decltype(gfc)::value, decltype(cst)::value>, grid, block, lds, st, g,
@@ -170,6 +168,8 @@ int launch_bwd_tile_t(KP g, const void* x, const void* go, const void* out, cons
       // at 96 / 160 bytes, profiles/r03_w_tile_backward_stores_ab.txt), workgroups of up to 640 threads (the variant
       // takes 96 registers: two such workgroups per compute unit)
       const bool cst = NHWC && G == 1 && g.C * (BF ? 2 : 4) >= 256 && npu <= 640;
+      snprintf(g_variant, sizeof(g_variant), "bwd_tile<R%d,%s,%s,%s%s%s>x%d", R, hot_name(g), BF ? "bf16" : "f32",
+               NHWC ? "nhwc" : "nchw", cst ? ",dense" : "", POOL ? ",pool" : "", nb);
       const std::true_type T_;
       const std::false_type F_;
       if constexpr (M == NFP_COSINE) {

@@ -80,6 +80,26 @@ def test_tile_kernels_bf16_storage(B, C, H, W, R, meas, mode, channels_last):
     assert rel_err(gx.float().cpu().numpy(), gref.cpu().numpy()) <= 2e-2
 
 
+@pytest.mark.parametrize("B,C,H,W,R,meas,mode,dtype,channels_last,dense", [
+    (160, 64, 28, 28, 1, "cosine", "reflect", torch.float32, False, False),
+    (160, 64, 28, 28, 1, "cosine", "reflect", torch.float32, True, True),     # 256-byte pixels: dense grad_x stores through LDS
+    (160, 64, 28, 28, 1, "norm", "zeros", torch.float32, True, True),
+    (128, 128, 28, 28, 1, "cosine", "replicate", torch.bfloat16, True, True),
+    (160, 32, 28, 28, 2, "cosine", "reflect", torch.float32, True, False),    # 128-byte pixels: shared loads, direct stores
+    (200, 16, 40, 40, 1, "gfc", "reflect", torch.float32, True, False)])
+def test_tile_kernels_one_thread_per_position_on_a_full_chip(B, C, H, W, R, meas, mode, dtype, channels_last, dense):
+    """Batches that fill the chip run ONE channel group per position — the form the MultiStage maps at B = 256 use, with
+    the output phase from registers, the wavefront-shared channels-last staging (a partial last wavefront included:
+    270 / 352 threads) and, for wide pixels, the dense grad_x stores.  Small test batches never get there."""
+    dev = torch.device("cuda:0")
+    out, gx, ref, gref, fv, bv = _run(B, C, H, W, R, meas, mode, dev, dtype=dtype, channels_last=channels_last)
+    assert fv.startswith("fwd_tile<") and bv.startswith("bwd_tile<"), (fv, bv)
+    assert (",dense" in bv) == dense, bv
+    to, tg = (TOL, TOL) if dtype == torch.float32 else (1e-2, 2e-2)
+    assert rel_err(out.float().cpu().numpy(), ref.cpu().numpy()) <= to, fv
+    assert rel_err(gx.float().cpu().numpy(), gref.cpu().numpy()) <= tg, bv
+
+
 def test_tile_kernels_dissimilarity_and_norm_quirk():
     dev = torch.device("cuda:0")
     out, gx, ref, gref, fv, bv = _run(2, 16, 40, 40, 1, "cosine", "reflect", dev, similarity=False)
