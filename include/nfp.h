@@ -143,8 +143,9 @@ int nfp_backward(const nfp_desc* d, const void* x, const void* grad_out, const v
  *   gap  [B,C] f32 = AdaptiveAvgPool2d(1)(x)                          NFP_Pooling.py:27
  *   nfpm [B,N] f32 = adaptive_avg_pool2d(NFPPooling(x), 1)            NFP_Pooling.py:29-31
  * out_map [B,N,Ho,Wo] (dtype of x) is also written: the backward needs it, callers may ignore it.
- * Served only where nfp_pool_supported(d) != 0 — cosine / L2 on "same" maps (stride 1, padding = R) of any size, NCHW or
- * channels-last, float32 or bf16 (maps of at most 512 pixels: with the descriptor's workspace set); the answer is a dry
+ * Served only where nfp_pool_supported(d) != 0 — cosine / dot / gfc / L2 / rmse on "same" maps (stride 1, padding = R),
+ * NCHW or channels-last, float32 or bf16: maps of at most 512 pixels with the descriptor's workspace set, larger maps
+ * with rows of up to about 200 (k = 3) / 120 (k = 5) pixels; the answer is a dry
  * run of both launchers, so a 1 means both nfp_pool_forward and nfp_pool_backward will launch.  Otherwise compose
  * nfp_forward with ordinary pooling.
  */

@@ -348,8 +348,9 @@ def _pool_saved_floats(x, layout, cfg, d):
 
 
 def nfp_pool_fused_ok(x, cfg):
-    """True when the fused GAP + pooled-NFP kernels can serve this call: "same" maps (stride 1, pad = R) of any size,
-    cosine or L2, float32 or bfloat16, images dense in NCHW or channels-last order."""
+    """True when the fused GAP + pooled-NFP kernels can serve this call: "same" maps (stride 1, pad = R; above 512 pixels:
+    rows of up to about 200 / 120 pixels for k = 3 / 5), cosine / dot / gfc / L2 / rmse, float32 or bfloat16, images dense in NCHW
+    or channels-last order.  (The library answers: a dry run of both launchers.)"""
     if not (x.is_cuda and x.dim() == 4 and x.dtype in _DTYPES):
         return False
     layout = _inner_layout(x)

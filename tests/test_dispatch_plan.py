@@ -84,6 +84,9 @@ def test_plan_does_not_launch_or_disturb_last_variant(lib):
     (dict(shape=(64, 64, 56, 56)), "fwd_tile<R1,cos,f32,nchw>x10", "bwd_tile<R1,cos,f32,nchw>x10"),     # > 512 px: row bands
     (dict(shape=(256, 16, 112, 112)), "fwd_tile<R1,cos,f32,nchw>x19", "bwd_tile<R1,cos,f32,nchw>x19"),
     (dict(shape=(2, 8, 100, 140)), "fwd_tile<R1,cos,f32,nchw>x50", "bwd_tile<R1,cos,f32,nchw>x50"),
+    (dict(shape=(2, 8, 20, 300)), "fwd_pairs", "bwd_direct"),                                          # rows too long for a band's threads
+    (dict(shape=(256, 64, 56, 56), channels_last=True), "fwd_tile<R1,cos,f32,nhwc>x10", "bwd_tile<R1,cos,f32,nhwc,dense>x10"),   # 256-byte pixels
+    (dict(shape=(256, 16, 112, 112), channels_last=True), "fwd_tile<R1,cos,f32,nhwc>x19", "bwd_tile<R1,cos,f32,nhwc>x19"),
     (dict(shape=(2, 8, 100, 140), measure="emd"), "fwd_pairs", "bwd_gather_banded"),                   # tables > LDS
     (dict(shape=(2, 16, 64, 64), mode="circular"), "fwd_pairs", "bwd_direct"),                        # wraps: no bands
 ])
