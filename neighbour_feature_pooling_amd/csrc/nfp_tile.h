@@ -37,6 +37,8 @@
 
 namespace nfp {
 
+constexpr int kPoolSub = 1;  // fused pooling tail: a band's pixels in this many segments, each with its own row of partial sums
+                             // (measured: 4 segments lose, 115 vs 100 us at [256,16,112,112] — every extra item is four DPP trees)
 constexpr int kTileKQ = 4;   // channel quads a thread stages per chunk (16 registers): a chunk is 4 * G * kTileKQ channels
 
 struct TileGeo {  // by value in kernarg
@@ -250,9 +252,10 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 // ---- forward ----------------------------------------------------------------------------------------------------------
 // POOL: the fused tail of models/NFP_Pooling.py:27-31 for large maps: besides the maps this band's share of the two
-// pooled sums goes to part[(b * nb + band)][C + N] (sums, not means); pool_fold joins the bands in a fixed order.
+// pooled sums goes to part[(b * nb + band) * kPoolSub + segment][C + N] (sums, not means); pool_fold joins the rows in a
+// fixed order.
 // GFC (nfp.py:265-276) differs from cosine in how a pair sum and the two norms combine (a reciprocal per output).
-// LDS: slab [Cc / 4][Ppb] float4 | pair sums [NF][npu] | per-position factor [npu] (| POOL: the band's maps [N][nbp]).
+// LDS: slab [Cc / 4][Ppb] float4 (POOL: later the band's maps [N][nbp]) | pair sums [NF][npu] | per-position factor [npu].
 // (k = 3: two workgroups of up to 1024 threads share a compute unit — 8 wavefronts per SIMD, 64 registers)
 template <int R, int M, bool BF, bool NHWC, bool POOL = false, bool GFC = false>
 __global__ void __launch_bounds__(1024, (R == 1 ? 8 : 4)) fwd_tile(const KP g, const TileGeo tg, const void* __restrict__ x,
@@ -270,7 +273,11 @@ __global__ void __launch_bounds__(1024, (R == 1 ? 8 : 4)) fwd_tile(const KP g, c
   const int W = g.W, P = g.P, v = ps.v;
   float4* slab = lds4;
   const int dump = (g.Cc >> 2) * Ppb;               // (a spare slot behind the slab)
-  float* Tt = (float*)(lds4 + dump + 1);            // [NF][npu] pair sums per direction, then the per-position factor
+  // (POOL: the band's map values [N][nbp], staged for the pooled sums, lie over the slab — dead by then; should they
+  // need more room than the slab has, the tables start behind them)
+  const int nbpA = (tg.rows - 2 * R) * g.W;
+  const int tt0 = POOL ? max(dump + 1, (N * nbpA + 3) >> 2) : dump + 1;
+  float* Tt = (float*)(lds4 + tt0);                 // [NF][npu] pair sums per direction, then the per-position factor
   float* Fq = Tt + NF * npu;
   const Rsrc xb = make_rsrc((const char*)x + (long long)b * g.sB * ES, (long long)g.C * P * ES);
   NFP_STAMP_INIT();
@@ -295,16 +302,17 @@ __global__ void __launch_bounds__(1024, (R == 1 ? 8 : 4)) fwd_tile(const KP g, c
     if (c0 + g.Cc < g.C) st.issue(g, ps, xb, G, c0 + g.Cc, min(g.Cc, g.C - c0 - g.Cc) >> 2, npu);
     if (c0 == 0) NFP_STAMP(2);
     if constexpr (POOL) {
-      // this band's share of sum over pixels of x[c]: wavefront w takes channel quads w, w + nw, ...; lanes stride over
-      // the band's pixels; fixed DPP tree; one writer per channel.  (FULL wavefronts only: the tree reads all 64 lanes;
-      // a workgroup's last wavefront may be partial)
+      // this band's share of sum over pixels of x[c]: (channel quad, segment of the band's pixels) items dealt over the
+      // FULL wavefronts (the DPP tree reads all 64 lanes; a workgroup's last wavefront may be partial); lanes stride over
+      // the segment's pixels; one writer per (segment, channel).  pool_fold joins segments and bands in a fixed order.
       const int t = ps.gl + G * v, lane = t & 63, wv = t >> 6, nw = (G * npu) >> 6;
-      const int nbp = (bd.y1 - bd.y0) * W;
-      float* pb = part + ((long long)b * tg.nb + band) * (g.C + N) + c0;
+      const int nbp = (bd.y1 - bd.y0) * W, seg = (nbp + kPoolSub - 1) / kPoolSub;
+      float* pb = part + ((long long)b * tg.nb + band) * kPoolSub * (g.C + N) + c0;
       if (wv < nw) {
-        for (int cq = wv; cq < ncq; cq += nw) {
+        for (int it = wv; it < ncq * kPoolSub; it += nw) {
+          const int cq = it / kPoolSub, sub = it - cq * kPoolSub, hi = min(nbp, (sub + 1) * seg);
           float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
-          for (int lp = lane; lp < nbp; lp += 64) {
+          for (int lp = sub * seg + lane; lp < hi; lp += 64) {
             const int yl = fdivi(lp, W), xl = lp - yl * W;
             const float4 q = slab[cq * Ppb + (yl + R) * Wu + xl + R];
             s4.x += q.x;
@@ -316,7 +324,7 @@ __global__ void __launch_bounds__(1024, (R == 1 ? 8 : 4)) fwd_tile(const KP g, c
           s4.y = wave_sum(s4.y);
           s4.z = wave_sum(s4.z);
           s4.w = wave_sum(s4.w);
-          if (lane == 63) *(float4*)(pb + 4 * cq) = s4;
+          if (lane == 63) *(float4*)(pb + sub * (g.C + N) + 4 * cq) = s4;
         }
       } else if (nw == 0 && t == 0) {  // (a workgroup below 64 threads: tiny maps, one thread adds them up)
         for (int cq = 0; cq < ncq; ++cq) {
@@ -329,7 +337,8 @@ __global__ void __launch_bounds__(1024, (R == 1 ? 8 : 4)) fwd_tile(const KP g, c
             s4.z += q.z;
             s4.w += q.w;
           }
-          *(float4*)(pb + 4 * cq) = s4;
+          for (int sub = 0; sub < kPoolSub; ++sub)
+            *(float4*)(pb + sub * (g.C + N) + 4 * cq) = sub == 0 ? s4 : make_float4(0.f, 0.f, 0.f, 0.f);
         }
       }
     }
@@ -377,8 +386,8 @@ __global__ void __launch_bounds__(1024, (R == 1 ? 8 : 4)) fwd_tile(const KP g, c
   NFP_STAMP(4);
   // outputs of the band's rows, by the position's own threads (lanes along a row: coalesced stores); the G lanes of a
   // position share the N taps
-  const int nbpA = (tg.rows - 2 * R) * W, lpf = (ps.vy - R) * W + ps.x;
-  float* vm = Fq + npu;  // (POOL) [N][nbpA]: the band's map values, for the pooled sums
+  const int lpf = (ps.vy - R) * W + ps.x;
+  float* vm = (float*)slab;  // (POOL) [N][nbpA]: the band's map values, for the pooled sums (every wavefront is past its sums)
   if (ps.own) {
     const int p = ps.y * W + ps.x;
     // (buffer stores: one offset register for all N maps of the pixel, the map through the scalar offset)
@@ -420,24 +429,24 @@ __global__ void __launch_bounds__(1024, (R == 1 ? 8 : 4)) fwd_tile(const KP g, c
       saved[(long long)b * P + p] = GFC ? Fp : __builtin_amdgcn_sqrtf(nrm);
   }
   if constexpr (POOL) {
-    // this band's share of sum over pixels of out[n]: wavefront w reduces map n = w, w + nw, ... over the band's pixels
-    // in a fixed order
+    // this band's share of sum over pixels of out[n]: (map, segment) items over the full wavefronts, a fixed order
     __syncthreads();
     const int t = ps.gl + G * v, lane = t & 63, wv = t >> 6, nw = (G * npu) >> 6;
-    const int nbp = (bd.y1 - bd.y0) * W;
-    float* pb = part + ((long long)b * tg.nb + band) * (g.C + N) + g.C;
+    const int nbp = (bd.y1 - bd.y0) * W, seg = (nbp + kPoolSub - 1) / kPoolSub;
+    float* pb = part + ((long long)b * tg.nb + band) * kPoolSub * (g.C + N) + g.C;
     if (wv < nw) {
-      for (int n = wv; n < N; n += nw) {
+      for (int it = wv; it < N * kPoolSub; it += nw) {
+        const int n = it / kPoolSub, sub = it - n * kPoolSub, hi = min(nbp, (sub + 1) * seg);
         float s = 0.f;
-        for (int i = lane; i < nbp; i += 64) s += vm[n * nbpA + i];
+        for (int i = sub * seg + lane; i < hi; i += 64) s += vm[n * nbpA + i];
         s = wave_sum(s);
-        if (lane == 63) pb[n] = s;
+        if (lane == 63) pb[sub * (g.C + N) + n] = s;
       }
     } else if (nw == 0 && t == 0) {
       for (int n = 0; n < N; ++n) {
         float s = 0.f;
         for (int i = 0; i < nbp; ++i) s += vm[n * nbpA + i];
-        pb[n] = s;
+        for (int sub = 0; sub < kPoolSub; ++sub) pb[sub * (g.C + N) + n] = sub == 0 ? s : 0.f;
       }
     }
   }
@@ -451,8 +460,19 @@ __global__ void __launch_bounds__(256) pool_fold(const float* __restrict__ part,
   const int CN = C + N;
   if (i >= (long long)B * CN) return;
   const int b = (int)(i / CN), k = (int)(i - (long long)b * CN);
+  // (the rows in a fixed order; eight loads in flight at a time — one dependent load per row is a latency chain: 19 rows
+  // took 13 us of a 35 us pooled tail)
+  const float* pr = part + (long long)b * nb * CN + k;
   float s = 0.f;
-  for (int j = 0; j < nb; ++j) s += part[((long long)b * nb + j) * CN + k];
+  int j = 0;
+  for (; j + 8 <= nb; j += 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = pr[(long long)(j + u) * CN];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  for (; j < nb; ++j) s += pr[(long long)j * CN];
   if (k < C)
     gap[(long long)b * C + k] = s * invP;
   else

@@ -90,8 +90,9 @@ int launch_fwd_tile_t(KP g, const void* x, void* out, float* saved, hipStream_t 
       const int rows = rb + 2 * R, npu = rows * Wu, nbp = rb * g.W;
       const int lg = tile_groups(g, nb, npu, kCap, g.C / 4), G = 1 << lg;
       const int ppb = nfp::band_row_slots((npu + 3) & ~3, lg);
-      const size_t tail = 16 + (size_t)(NF + 1) * npu * 4 + (POOL ? (size_t)N * nbp * 4 : 0);
-      if (tail + (size_t)ppb * 16 > budget) continue;
+      const size_t tail = 16 + (size_t)(NF + 1) * npu * 4;                      // spare slot, pair sums, factors
+      const size_t vmb = POOL ? (((size_t)N * nbp + 3) / 4) * 16 : 0;            // pooled: the band's maps, over the slab
+      if (tail + std::max((size_t)ppb * 16, vmb) > budget) continue;
       int ncq = (int)((budget - tail) / ((size_t)ppb * 16));
       ncq = std::min(ncq, std::min(nfp::kTileKQ * G, g.C / 4));
       if (ncq < 1) continue;
@@ -103,9 +104,9 @@ int launch_fwd_tile_t(KP g, const void* x, void* out, float* saved, hipStream_t 
         g.Tc = ncq >= 4 ? 2 : (ncq >= 2 ? 1 : 0);
         g.Cc = 4 << g.Tc;
       }
-      const size_t lds = (size_t)(g.Cc / 4) * ppb * 16 + tail;
+      const size_t lds = std::max((size_t)(g.Cc / 4) * ppb * 16, vmb) + tail;
       nfp::TileGeo tg = {nb, rows, Wu, ppb, 1};
-      if (nb_out) *nb_out = nb;
+      if (nb_out) *nb_out = POOL ? nb * nfp::kPoolSub : nb;   // (pooled: rows of partial sums per image)
       snprintf(g_variant, sizeof(g_variant), "fwd_tile<R%d,%s,%s,%s%s>x%d", R, hot_name(g), BF ? "bf16" : "f32",
                NHWC ? "nhwc" : "nchw", POOL ? ",pool" : "", nb);
       const dim3 grid((unsigned)(g.B * nb)), block(G, Wu, rows);

@@ -23,13 +23,20 @@ def case(name, fwd, x, grads_of):
         torch.autograd.grad(outs, x, gos, retain_graph=True)
         torch.cuda.synchronize()
         bv = L.nfp_last_variant().decode()
-        tf = time_kernel_graph(fwd, 50, s)
-        tb = time_kernel_graph(lambda: torch.autograd.grad(outs, x, gos, retain_graph=True), 50, s)
+        reps = 50 if x.numel() < (1 << 24) else 10
+        tf = time_kernel_graph(fwd, reps, s)
+        tb = time_kernel_graph(lambda: torch.autograd.grad(outs, x, gos, retain_graph=True), reps, s)
     print(json.dumps({"case": name, "fwd_us": round(tf, 2), "bwd_us": round(tb, 2), "fwd": fv, "bwd": bv}))
 
 
+# ... and the maps MobileNetV3_MultiStageNFP averages at once (texture_pooling.py:249-252): row-band kernels + pool_fold
 for shape, dt, cl, R, meas in (((64, 512, 7, 7), torch.float32, False, 1, "cosine"),
-                               ((256, 192, 14, 14), torch.bfloat16, True, 2, "norm")):
+                               ((256, 192, 14, 14), torch.bfloat16, True, 2, "norm"),
+                               ((256, 16, 112, 112), torch.float32, False, 1, "cosine"),
+                               ((256, 24, 56, 56), torch.float32, False, 1, "cosine"),
+                               ((256, 40, 28, 28), torch.float32, False, 1, "cosine"),
+                               ((256, 16, 112, 112), torch.bfloat16, True, 1, "cosine"),
+                               ((256, 40, 28, 28), torch.bfloat16, True, 1, "cosine")):
     x = torch.randn(*shape, device=dev).to(dt)
     if cl:
         x = x.contiguous(memory_format=torch.channels_last)
