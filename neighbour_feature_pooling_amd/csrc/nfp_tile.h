@@ -483,7 +483,7 @@ __global__ void __launch_bounds__(256) pool_fold(const float* __restrict__ part,
 // POOL: grad_out is not a map: go[b,n,p] = gnfpm[b,n] / P for every p, and every grad_x[b,c,p] also gets ggap[b,c] / P.
 // GFC: the general post-factors of nfp_common.h::cross_f / diag_f (a reciprocal per window slot); cosine and dot keep the
 // plain product of the two per-pixel factors.
-// LDS (floats): ipn [PL] | pair values [N][PL] (cosine: sg = +-grad_out; L2: c = -+g / d) — PL = (rows + 2R) * Wu: R
+// LDS (floats): guard [4] | ipn [PL] | pair values [N][PL] | guard [4] (cosine: sg = +-grad_out; L2: c = -+g / d) — PL = (rows + 2R) * Wu: R
 // rows of ZEROS above and below the band in every plane, so that a tap at a constant offset of ANY position reads a
 // value (a column past the row's end lands in the ring columns of the next row: zeros too).  After phase A the pair
 // values are dead: the x slab lies over them, and behind the slab the window rows of the ring positions
@@ -508,8 +508,10 @@ __global__ void __launch_bounds__(1024, (R == 1 ? (CST ? 5 : 8) : 4)) bwd_tile(c
   const int G = blockDim.x, Wu = tg.Wu, Ppb = tg.Ppb, npu = tg.rows * Wu, PL = (tg.rows + 2 * R) * Wu;
   const int W = g.W, H = g.H, P = g.P, v = ps.v;
   const int cb0 = cblk * g.Cwg, cb1 = min(g.C, cb0 + g.Cwg);
-  float* ipn = (float*)lds4 + R * Wu;                       // ipn[v], margins at v < 0 and v >= npu
-  float* pvb = (float*)lds4 + ((PL + 3) & ~3);
+  // (four zeroed guard words in front of ipn, the padding behind it and four words behind the last plane zeroed too: the
+  // corner positions' diagonal taps reach one word past a margin)
+  float* ipn = (float*)lds4 + 4 + R * Wu;                   // ipn[v], margins at v < 0 and v >= npu
+  float* pvb = (float*)lds4 + 4 + ((PL + 3) & ~3);
   float* PV = pvb + R * Wu;                                 // plane n at PV + n * PL
   float4* slab = (float4*)pvb;
   const int dump = (g.Cc >> 2) * Ppb;                       // (a spare slot behind the slab)
@@ -581,6 +583,11 @@ __global__ void __launch_bounds__(1024, (R == 1 ? (CST ? 5 : 8) : 4)) bwd_tile(c
       ipr = GFC ? nrm : ip;                                                     // (GFC: the norm itself — nfp_common.h::cross_f)
       ipn[v] = ipr;
       dfn = nrm > 0.f ? -(GFC ? 1.f : g.nuf * ip) * __builtin_amdgcn_rcpf(nrm) : 0.f;
+    }
+    if (v < 4 && ps.gl == 0) {
+      ((float*)lds4)[v] = 0.f;
+      ((float*)lds4)[4 + PL + v] = 0.f;   // (padding, or the first words of plane 0's zero row)
+      pvb[N * PL + v] = 0.f;
     }
     // the zero rows above and below the band, every plane
     if (ps.vy < R || ps.vy >= tg.rows - R) {

@@ -133,8 +133,8 @@ int launch_bwd_tile_t(KP g, const void* x, const void* go, const void* out, cons
       const int rb = tile_bands(g, rb0, nb);
       if (rb < 1) break;
       const int rows = rb + 2 * R, npu = rows * Wu, PL = (rows + 2 * R) * Wu;
-      const size_t fixed = (size_t)((PL + 3) & ~3) * 4;                       // ipn
-      const size_t pv = (size_t)N * PL * 4;                                   // pair values, every plane with its zero rows
+      const size_t fixed = (size_t)(4 + ((PL + 3) & ~3)) * 4;                 // guard words, ipn
+      const size_t pv = (size_t)(N * PL + 4) * 4;                             // pair values, every plane with its zero rows; guard
       const size_t wr = 16 + (size_t)((rows * 2 * R + 2 * R * g.W) * K2 + 4 * K2) * 4;   // spare slot, ring rows (+ slack)
       if (fixed + pv > budget) continue;
       // channel blocks: enough workgroups to fill the chip when images x bands do not
