@@ -53,13 +53,15 @@ struct TileGeo {  // by value in kernarg
 // image per XCD and all `per` items (bands x channel blocks) of an image follow each other on it.  Bijective for any B
 // (the last group may hold fewer than 8 images; its placement is then only partly XCD-aligned: speed, not correctness).
 __device__ __forceinline__ void tile_ids(int id, int B, int per, int& b, int& item) {
-  // (wave-uniform, once per workgroup; fdivi: four vector instructions where a scalar integer division takes ~40.
-  // Exact below 2^22 workgroups)
+  // (wave-uniform, once per workgroup; fdivi: four vector instructions where a scalar integer division takes ~40.  Exact
+  // while quotient * 2^-22 stays below its 0.5 / divisor margin: the launchers keep a grid at or below kTileMaxGrid
+  // workgroups and split larger batches into several launches)
   const int grp = __builtin_amdgcn_readfirstlane(fdivi(id, 8 * per)), l = id - grp * 8 * per;   // (back to scalar registers)
   const int m = min(8, B - 8 * grp);
   item = __builtin_amdgcn_readfirstlane(fdivi(l, m));
   b = 8 * grp + l - item * m;
 }
+constexpr int kTileMaxGrid = 1 << 18;
 
 template <int R>
 struct TileBand {
@@ -483,7 +485,7 @@ __global__ void __launch_bounds__(256) pool_fold(const float* __restrict__ part,
 // POOL: grad_out is not a map: go[b,n,p] = gnfpm[b,n] / P for every p, and every grad_x[b,c,p] also gets ggap[b,c] / P.
 // GFC: the general post-factors of nfp_common.h::cross_f / diag_f (a reciprocal per window slot); cosine and dot keep the
 // plain product of the two per-pixel factors.
-// LDS (floats): guard [4] | ipn [PL] | pair values [N][PL] | guard [4] (cosine: sg = +-grad_out; L2: c = -+g / d) — PL = (rows + 2R) * Wu: R
+// LDS (floats): ipn [PL] | pair values [N][PL] | guard [4] (cosine: sg = +-grad_out; L2: c = -+g / d) — PL = (rows + 2R) * Wu: R
 // rows of ZEROS above and below the band in every plane, so that a tap at a constant offset of ANY position reads a
 // value (a column past the row's end lands in the ring columns of the next row: zeros too).  After phase A the pair
 // values are dead: the x slab lies over them, and behind the slab the window rows of the ring positions
@@ -508,10 +510,11 @@ __global__ void __launch_bounds__(1024, (R == 1 ? (CST ? 5 : 8) : 4)) bwd_tile(c
   const int G = blockDim.x, Wu = tg.Wu, Ppb = tg.Ppb, npu = tg.rows * Wu, PL = (tg.rows + 2 * R) * Wu;
   const int W = g.W, H = g.H, P = g.P, v = ps.v;
   const int cb0 = cblk * g.Cwg, cb1 = min(g.C, cb0 + g.Cwg);
-  // (four zeroed guard words in front of ipn, the padding behind it and four words behind the last plane zeroed too: the
-  // corner positions' diagonal taps reach one word past a margin)
-  float* ipn = (float*)lds4 + 4 + R * Wu;                   // ipn[v], margins at v < 0 and v >= npu
-  float* pvb = (float*)lds4 + 4 + ((PL + 3) & ~3);
+  // (a corner position's diagonal taps reach R words past a margin: the padding behind ipn — which is what lies in front
+  // of plane 0 — and four words behind the last plane are zeroed too.  In front of ipn itself there is nothing: such a
+  // read feeds a window slot nobody fetches, through a product with an exact 0.)
+  float* ipn = (float*)lds4 + R * Wu;                       // ipn[v], margins at v < 0 and v >= npu
+  float* pvb = (float*)lds4 + ((PL + 3) & ~3);
   float* PV = pvb + R * Wu;                                 // plane n at PV + n * PL
   float4* slab = (float4*)pvb;
   const int dump = (g.Cc >> 2) * Ppb;                       // (a spare slot behind the slab)
@@ -584,13 +587,11 @@ __global__ void __launch_bounds__(1024, (R == 1 ? (CST ? 5 : 8) : 4)) bwd_tile(c
       ipn[v] = ipr;
       dfn = nrm > 0.f ? -(GFC ? 1.f : g.nuf * ip) * __builtin_amdgcn_rcpf(nrm) : 0.f;
     }
-    if (v < 4 && ps.gl == 0) {
-      ((float*)lds4)[v] = 0.f;
-      ((float*)lds4)[4 + PL + v] = 0.f;   // (padding, or the first words of plane 0's zero row)
-      pvb[N * PL + v] = 0.f;
-    }
-    // the zero rows above and below the band, every plane
+    // the zero rows above and below the band, every plane (and the guard words: the first four positions' threads)
     if (ps.vy < R || ps.vy >= tg.rows - R) {
+      const int gw = min(v, 3);
+      ((float*)lds4)[PL + gw] = 0.f;   // (padding, or the first words of plane 0's zero row)
+      pvb[N * PL + gw] = 0.f;
       const int m = ps.vy < R ? v - R * Wu : v + R * Wu;
       if (M == NFP_COSINE) ipn[m] = 0.f;
 #pragma unroll
@@ -612,7 +613,8 @@ __global__ void __launch_bounds__(1024, (R == 1 ? (CST ? 5 : 8) : 4)) bwd_tile(c
       const float ipq = (ipn + v + dy * Wu - R)[dx + R];
       const float S = w[j] + c2;
       if (GFC) {
-        D = fmaf(S * sv[n], diag_f(g, ipr, ipq), D);
+        const float ts = S * sv[n];   // (exactly 0 for a tap that leaves the band: whatever factor was read there stays out)
+        D = ts != 0.f ? fmaf(ts, diag_f(g, ipr, ipq), D) : D;
         w[j] = cross_f(g, ipr, ipq) * S;
       } else {
         D = fmaf(S, sv[n], D);

@@ -109,11 +109,25 @@ int launch_fwd_tile_t(KP g, const void* x, void* out, float* saved, hipStream_t 
       if (nb_out) *nb_out = POOL ? nb * nfp::kPoolSub : nb;   // (pooled: rows of partial sums per image)
       snprintf(g_variant, sizeof(g_variant), "fwd_tile<R%d,%s,%s,%s%s>x%d", R, hot_name(g), BF ? "bf16" : "f32",
                NHWC ? "nhwc" : "nchw", POOL ? ",pool" : "", nb);
-      const dim3 grid((unsigned)(g.B * nb)), block(G, Wu, rows);
-      if constexpr (M == NFP_COSINE) {
-        if (g.gfc) return launch("fwd_tile", fwd_tile<R, M, BF, NHWC, POOL, true>, grid, block, lds, st, g, tg, x, out, saved, part);
+      const dim3 block(G, Wu, rows);
+      // (tile_ids' exact range: batches beyond kTileMaxGrid workgroups go out as several launches, images in order)
+      const int es = BF ? 2 : 4, bmax = std::max(8, (nfp::kTileMaxGrid / nb) & ~7);
+      for (int b0 = 0; b0 < g.B; b0 += bmax) {
+        KP gs = g;
+        gs.B = std::min(bmax, g.B - b0);
+        const dim3 grid((unsigned)(gs.B * nb));
+        const void* xs = (const char*)x + (long long)b0 * g.sB * es;
+        void* os = (char*)out + (long long)b0 * N * g.P * es;
+        float* ss = saved ? saved + (long long)b0 * g.P : nullptr;
+        float* ps = part ? part + (long long)b0 * nb * nfp::kPoolSub * (g.C + N) : nullptr;
+        int rc;
+        if (M == NFP_COSINE && g.gfc)
+          rc = launch("fwd_tile", fwd_tile<R, M, BF, NHWC, POOL, M == NFP_COSINE>, grid, block, lds, st, gs, tg, xs, os, ss, ps);
+        else
+          rc = launch("fwd_tile", fwd_tile<R, M, BF, NHWC, POOL, false>, grid, block, lds, st, gs, tg, xs, os, ss, ps);
+        if (rc != NFP_OK) return rc;
       }
-      return launch("fwd_tile", fwd_tile<R, M, BF, NHWC, POOL, false>, grid, block, lds, st, g, tg, x, out, saved, part);
+      return NFP_OK;
     }
   }
   return kNotApplicable;
@@ -133,7 +147,7 @@ int launch_bwd_tile_t(KP g, const void* x, const void* go, const void* out, cons
       const int rb = tile_bands(g, rb0, nb);
       if (rb < 1) break;
       const int rows = rb + 2 * R, npu = rows * Wu, PL = (rows + 2 * R) * Wu;
-      const size_t fixed = (size_t)(4 + ((PL + 3) & ~3)) * 4;                 // guard words, ipn
+      const size_t fixed = (size_t)((PL + 3) & ~3) * 4;                       // ipn
       const size_t pv = (size_t)(N * PL + 4) * 4;                             // pair values, every plane with its zero rows; guard
       const size_t wr = 16 + (size_t)((rows * 2 * R + 2 * R * g.W) * K2 + 4 * K2) * 4;   // spare slot, ring rows (+ slack)
       if (fixed + pv > budget) continue;
@@ -159,11 +173,7 @@ int launch_bwd_tile_t(KP g, const void* x, const void* go, const void* out, cons
       }
       const size_t lds = fixed + std::max(pv, (size_t)(g.Cc / 4) * ppb * 16 + wr);
       nfp::TileGeo tg = {nb, rows, Wu, ppb, S};
-      const dim3 grid((unsigned)(g.B * nb * S)), block(G, Wu, rows);
-      auto go_ = [&](auto gfc, auto cst) {
-        return launch("bwd_tile", bwd_tile<R, M, BF, NHWC, POOL, decltype(gfc)::value, decltype(cst)::value>, grid, block, lds, st, g,
-                      tg, x, go, out, saved, gx, ggap, gnfpm);
-      };
+      const dim3 block(G, Wu, rows);
       // dense grad_x stores through LDS (nfp_tile.h, phase B): channels-last with one thread per position, pixels of 256
       // bytes and more (below, the scattered 16-byte stores of a pixel complete their cache lines soon enough: measured
       // at 96 / 160 bytes, profiles/r03_w_tile_backward_stores_ab.txt), workgroups of up to 640 threads (the variant
@@ -173,18 +183,37 @@ int launch_bwd_tile_t(KP g, const void* x, const void* go, const void* out, cons
                NHWC ? "nhwc" : "nchw", cst ? ",dense" : "", POOL ? ",pool" : "", nb);
       const std::true_type T_;
       const std::false_type F_;
-      if constexpr (M == NFP_COSINE) {
-        if (g.gfc) {
-          if constexpr (NHWC) {
-            if (cst) return go_(T_, T_);
+      const int es = BF ? 2 : 4, bmax = std::max(8, (nfp::kTileMaxGrid / (nb * S)) & ~7);
+      for (int b0 = 0; b0 < g.B; b0 += bmax) {   // (tile_ids' exact range: see launch_fwd_tile_t)
+        KP gs = g;
+        gs.B = std::min(bmax, g.B - b0);
+        const dim3 grid((unsigned)(gs.B * nb * S));
+        const void* xs = (const char*)x + (long long)b0 * g.sB * es;
+        const void* gos = go ? (const char*)go + (long long)b0 * N * g.P * es : nullptr;
+        const void* os = (const char*)out + (long long)b0 * N * g.P * es;
+        const float* ss = saved ? saved + (long long)b0 * g.P : nullptr;
+        void* gxs = (char*)gx + (long long)b0 * g.gB * es;
+        const float* ggs = ggap ? ggap + (long long)b0 * g.C : nullptr;
+        const float* gns = gnfpm ? gnfpm + (long long)b0 * N : nullptr;
+        auto go_ = [&](auto gfc, auto cstv) {
+          return launch("bwd_tile", bwd_tile<R, M, BF, NHWC, POOL, decltype(gfc)::value, decltype(cstv)::value>, grid, block, lds, st,
+                        gs, tg, xs, gos, os, ss, gxs, ggs, gns);
+        };
+        int rc;
+        if (M == NFP_COSINE && g.gfc) {
+          if constexpr (M == NFP_COSINE) {
+            if constexpr (NHWC) rc = cst ? go_(T_, T_) : go_(T_, F_);
+            else rc = go_(T_, F_);
+          } else {
+            rc = go_(F_, F_);
           }
-          return go_(T_, F_);
+        } else {
+          if constexpr (NHWC) rc = cst ? go_(F_, T_) : go_(F_, F_);
+          else rc = go_(F_, F_);
         }
+        if (rc != NFP_OK) return rc;
       }
-      if constexpr (NHWC) {
-        if (cst) return go_(F_, T_);
-      }
-      return go_(F_, F_);
+      return NFP_OK;
     }
   }
   return kNotApplicable;
