@@ -41,6 +41,7 @@ inline void publish_variant() {
 struct Switches {
   std::atomic<int> fwd_scalar{0}, bwd_atomic{0}, bwd_bands{0}, force_generic{0}, mfma{1}, tile_first{0};
   std::atomic<int> tile_wgs{0}, tile_lds_kb{0}, tile_cap{0};   // A/B overrides of the row-band launchers' constants (0: built-in)
+  std::atomic<int> tile_max_grid{0};                           // (tests: a smaller launch-splitting threshold)
 };
 inline Switches g_sw;
 #ifndef NFP_MFMA_DEFAULT
@@ -64,6 +65,7 @@ inline void read_env() {
   g_sw.tile_wgs = num("NFP_TILE_WGS");
   g_sw.tile_lds_kb = num("NFP_TILE_LDS_KB");
   g_sw.tile_cap = num("NFP_TILE_CAP");
+  g_sw.tile_max_grid = num("NFP_TILE_MAX_GRID");
 }
 
 inline int fail(int code, const char* fmt, ...) {

@@ -22,6 +22,7 @@ namespace {
 #endif
 int tile_wgs() { return g_sw.tile_wgs > 0 ? (int)g_sw.tile_wgs : NFP_TILE_WGS; }
 size_t tile_lds() { return (size_t)(g_sw.tile_lds_kb > 0 ? (int)g_sw.tile_lds_kb : NFP_TILE_LDS_KB) * 1024; }
+int tile_max_grid() { return g_sw.tile_max_grid > 0 ? std::min((int)g_sw.tile_max_grid, nfp::kTileMaxGrid) : nfp::kTileMaxGrid; }
 int tile_cap(int dflt) { return g_sw.tile_cap > 0 ? std::min((int)g_sw.tile_cap, 1024) : dflt; }
 bool tile_geometry(const KP& g) {
   if (g.stride != 1 || g.dil != 1 || g.pad != g.R || g.mode == NFP_PAD_CIRCULAR || g.rs == 12) return false;
@@ -111,7 +112,7 @@ int launch_fwd_tile_t(KP g, const void* x, void* out, float* saved, hipStream_t 
                NHWC ? "nhwc" : "nchw", POOL ? ",pool" : "", nb);
       const dim3 block(G, Wu, rows);
       // (tile_ids' exact range: batches beyond kTileMaxGrid workgroups go out as several launches, images in order)
-      const int es = BF ? 2 : 4, bmax = std::max(8, (nfp::kTileMaxGrid / nb) & ~7);
+      const int es = BF ? 2 : 4, bmax = std::max(8, (tile_max_grid() / nb) & ~7);
       for (int b0 = 0; b0 < g.B; b0 += bmax) {
         KP gs = g;
         gs.B = std::min(bmax, g.B - b0);
@@ -183,7 +184,7 @@ int launch_bwd_tile_t(KP g, const void* x, const void* go, const void* out, cons
                NHWC ? "nhwc" : "nchw", cst ? ",dense" : "", POOL ? ",pool" : "", nb);
       const std::true_type T_;
       const std::false_type F_;
-      const int es = BF ? 2 : 4, bmax = std::max(8, (nfp::kTileMaxGrid / (nb * S)) & ~7);
+      const int es = BF ? 2 : 4, bmax = std::max(8, (tile_max_grid() / (nb * S)) & ~7);
       for (int b0 = 0; b0 < g.B; b0 += bmax) {   // (tile_ids' exact range: see launch_fwd_tile_t)
         KP gs = g;
         gs.B = std::min(bmax, g.B - b0);

@@ -100,6 +100,43 @@ def test_tile_kernels_one_thread_per_position_on_a_full_chip(B, C, H, W, R, meas
     assert rel_err(gx.float().cpu().numpy(), gref.cpu().numpy()) <= tg, bv
 
 
+def test_batches_beyond_the_exact_id_range_go_out_as_several_launches(monkeypatch):
+    """The row-band kernels map workgroup ids to (image, band) with a float reciprocal that is exact up to 2^18
+    workgroups; the launchers split larger batches into several launches.  With the threshold lowered (test knob) the
+    split path runs at a test-sized batch: same kernels on slices of the batch, bitwise the same result."""
+    import os
+    from neighbour_feature_pooling_amd import NFPPooling, _abi
+    from neighbour_feature_pooling_amd.functional import nfp_pool
+    dev = torch.device("cuda:0")
+    L = _abi.load()
+    m = NFPPooling(16, R=1, measure="cosine", padding=1)
+    x = torch.randn(41, 16, 30, 34, device=dev, requires_grad=True)
+    go = torch.randn(41, 8, 30, 34, device=dev)
+
+    def run():
+        n0 = L.nfp_launch_count()
+        o = m(x)
+        n1 = L.nfp_launch_count()
+        g, = torch.autograd.grad(o, x, go)
+        pg, pn = nfp_pool(x, m.config)
+        gp, = torch.autograd.grad(pg.sum() + (pn * pn).sum(), x)
+        torch.cuda.synchronize()
+        return o.detach().clone(), g.clone(), pg.detach().clone(), pn.detach().clone(), gp.clone(), n1 - n0
+
+    ref = run()
+    assert ref[5] == 1
+    monkeypatch.setenv("NFP_TILE_MAX_GRID", "64")
+    L.nfp_reload_env()
+    try:
+        got = run()
+    finally:
+        monkeypatch.delenv("NFP_TILE_MAX_GRID")
+        L.nfp_reload_env()
+    assert got[5] > 1, "the forward did not split"
+    for a, b in zip(ref[:5], got[:5]):
+        assert torch.equal(a, b)
+
+
 def test_tile_kernels_dissimilarity_and_norm_quirk():
     dev = torch.device("cuda:0")
     out, gx, ref, gref, fv, bv = _run(2, 16, 40, 40, 1, "cosine", "reflect", dev, similarity=False)
