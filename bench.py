@@ -21,6 +21,8 @@ Two legs, both timed over exactly K steps between barriers:
     of x alone, a fresh grad_x / out per step, and a 512 MiB fill right before the clock starts: x, grad_out and
     grad_x are HBM traffic (within a step the backward re-reads the x its forward read microseconds before).  The
     HBM roofline fraction is quoted on THIS leg's kernel times, never on the cache-resident ones.
+Beside them (`--no-extras` skips these): the same kernels at a saturating batch, and `large_maps` — the module on the
+maps above 512 pixels MobileNetV3_MultiStageNFP feeds it at B = 256 (row-band kernels), per-kernel event times.
 The K timed steps are captured once into a HIP graph and replayed (`--launch eager` times plain launches
 instead): a step is ~11 us of GPU work, far below the host cost of two Python->ctypes->hipLaunch round trips.
 """
@@ -56,7 +58,7 @@ def parse(argv=None):
     ap.add_argument("--layout", choices=["nchw", "nhwc"], default="nchw")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
-    ap.add_argument("--no-extras", action="store_true", help="skip the cache-resident, ReLU-input, saturating-batch and "
+    ap.add_argument("--no-extras", action="store_true", help="skip the cache-resident, ReLU-input, saturating-batch, large-map and "
                     "live-traffic legs: every NFP launch of the process then belongs to the rotating leg, so a rocprofv3 "
                     "--kernel-trace --stats summary of the run averages exactly the launches `roofline` is quoted on")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)  # run under rocprofv3 --pmc by bench.py itself
@@ -574,6 +576,28 @@ def main():
                                        "bwd_frac_of_peak": round(big.bb / bb_ / 1e3 / HBM_PEAK_GBS, 4),
                                        "value": round(4096 * S * S / (bf_ + bb_), 1), "unit": "Mpixels/s (kernel time)"}
             del big, o
+            # the maps above 512 pixels that MobileNetV3_MultiStageNFP feeds the same module (texture_pooling.py:211-268) at
+            # B = 256: the row-band kernels (csrc/nfp_tile.h), each kernel between its own events, three rotating input sets
+            import copy
+            lm = []
+            for C_, S_ in ((16, 112), (24, 56), (40, 28)):
+                a2 = copy.copy(args)
+                a2.channels, a2.size = C_, S_
+                wl = Workload(a2, dev, rank, batch=256, sets=3)
+                lf, lb, _, _ = wl.kernel_events(timer, stream, rounds=2)
+                with torch.cuda.stream(stream):
+                    o = wl.m(wl.x[0])
+                    lfv = L.nfp_last_variant().decode()
+                    torch.autograd.grad(o, wl.x[0], wl.go[0])
+                    torch.cuda.synchronize()
+                    lbv = L.nfp_last_variant().decode()
+                lm.append({"shape": [256, C_, S_, S_], "forward_us": round(lf, 2), "backward_us": round(lb, 2),
+                           "forward_variant": lfv, "backward_variant": lbv,
+                           "fwd_frac_of_peak": round(wl.fb / lf / 1e3 / HBM_PEAK_GBS, 4),
+                           "bwd_frac_of_peak": round(wl.bb / lb / 1e3 / HBM_PEAK_GBS, 4)})
+                del wl, o
+                torch.cuda.empty_cache()
+            res["large_maps"] = lm
         if world == 1 and not args.no_cpu_baseline:
             res["unfold_path_same_gpu"] = unfold_on_gpu(args, dev)
             res["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
