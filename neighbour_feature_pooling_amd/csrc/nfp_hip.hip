@@ -392,9 +392,18 @@ int launch_fwd_band_t(KP g, const void* x, void* out, float* saved, hipStream_t 
   nb = (g.H + rb - 1) / rb;
   const int psm = std::min(g.P, (rb + g.R) * g.W);          // most pixels a band stages
   // channel groups: a power of two (adjacent lanes, joined by DPP), as many as kBandT threads and C allow, <= 32
-  // (up to one workgroup per CU, latency counts: all the threads a workgroup may have; beyond, the chip is busy and
-  // every extra thread's index work is paid for: half of them)
-  const int tcap = (long long)g.B * nb > 256 ? kBandT / 2 : kBandT;
+  // (up to one workgroup per CU, latency counts: all the threads a workgroup may have.  Beyond one workgroup per CU latency no longer counts and every extra thread's index work is paid for: half the
+  // threads on half-size slabs, two workgroups per CU; from four workgroups per CU on, a quarter — four 256-thread
+  // workgroups overlap each other's load / sum phases better than two of 512: [4096,512,7,7] cold 91.5 -> 85.4 us, [1024,…]
+  // 27.5 -> 26.2; an eighth is no better.  -DNFP_BAND_SAT_SHIFT=1 builds the old arm)
+#ifndef NFP_BAND_SAT_SHIFT
+#define NFP_BAND_SAT_SHIFT 2
+#endif
+  // (a band of more pixels than a quarter workgroup has threads stays at two per CU — the registers of 104-VGPR wavefronts
+  // hold 1024 threads per CU, whatever the slabs: [2048,64,20,20] 63 vs 73 us)
+  const long long nwg = (long long)g.B * nb;
+  const int sat = nwg > 256 ? ((nwg >= 1024 && psm <= (kBandT >> NFP_BAND_SAT_SHIFT)) ? NFP_BAND_SAT_SHIFT : 1) : 0;
+  const int tcap = kBandT >> sat;
   int lg = 0;
   while (lg < 5 && (2 << lg) * psm <= tcap && (2 << lg) <= g.C / 4) ++lg;
   g.G = 1 << lg;
@@ -404,7 +413,7 @@ int launch_fwd_band_t(KP g, const void* x, void* out, float* saved, hipStream_t 
                                                                        // the bank padding of band_row_slots included
   // up to one workgroup per CU the whole band is staged at once; beyond that, half-size slabs let two workgroups share a
   // CU and overlap each other's load / sum phases ([4096,512,7,7]: 91 vs 118 us)
-  const int budget = (long long)g.B * nb > 256 ? NFP_FWD_SLAB_KB * 512 : NFP_FWD_SLAB_KB * 1024;
+  const int budget = (NFP_FWD_SLAB_KB * 1024) >> sat;
   int ncq = budget / (ppb * 16);
   ncq = std::min(ncq, NHWC ? kBandRN * g.G : (kBandRB * T) / nqb);
   if (ncq < 1) return kNotApplicable;

@@ -514,6 +514,9 @@ def _sweep_cases():
             cases.append((B, C, H, W, R, meas, mode))
     cases += [(2, 2048, 7, 7, 1, "cosine", "reflect"),      # ResNet50_NFPPooling width (texture_pooling.py:547-561)
               (300, 64, 7, 7, 1, "cosine", "reflect"),       # more images than CUs: two workgroups per CU
+              (1100, 32, 7, 7, 1, "cosine", "reflect"),      # from four per CU on: quarter-size forward workgroups
+              (1030, 16, 14, 14, 2, "norm", "zeros"),        # ... 196 pixels in 256 threads
+              (1030, 8, 20, 20, 1, "cosine", "replicate"),   # ... 400 pixels: stays at two per CU
               (5, 1000, 3, 3, 1, "norm", "zeros"),
               (1, 4, 4, 1, 1, "cosine", "replicate") if False else (1, 4, 4, 4, 1, "cosine", "replicate"),
               (3, 516, 9, 9, 2, "cosine", "reflect")]
