@@ -469,12 +469,23 @@ int launch_bwd_fast_t(KP g, const void* x, const void* go, const void* out, cons
   if (S < 1) S = 1;
   g.Cwg = round4((g.C + S - 1) / S);
   S = (g.C + g.Cwg - 1) / g.Cwg;
-  g.G = kBwdThreads / g.P;
+  // From four workgroups per CU on (k = 3): quarter-size workgroups, four per CU (128 registers: 1024 threads per CU
+  // either way) — they overlap each other's phases better than two of 512: [4096,64,7,7] 45 -> 33 us, [4096,512,7,7] 176 ->
+  // 168, [1024,256,14,14] 100 -> 94.  Not k = 5: its 13-entry-per-pixel phase A on 256 threads doubles the kernel
+  // ([2048,192,14,14] 290 -> 486 us).  (-DNFP_BWD_SAT_T=512 builds the old arm.)
+#ifndef NFP_BWD_SAT_T
+#define NFP_BWD_SAT_T 256
+#endif
+#ifndef NFP_BWD_SAT_SLAB
+#define NFP_BWD_SAT_SLAB 2
+#endif
+  const bool satb = K2 <= 9 && (long long)g.B * S >= 1024 && g.P <= NFP_BWD_SAT_T && NFP_BWD_SAT_T < kBwdThreads;
+  g.G = (satb ? NFP_BWD_SAT_T : kBwdThreads) / g.P;
   if (g.G < 1) g.G = 1;
   if (g.G > g.Cwg / 4) g.G = g.Cwg / 4;
   int T = ((g.P * g.G + 63) / 64) * 64;
   // large batches (one workgroup per image, several images per CU over time): fewer, larger chunks win
-  const int bbudget = (S == 1 && g.B > 256) ? 2 * kSlabBudgetBwd : kSlabBudgetBwd;
+  const int bbudget = satb ? NFP_BWD_SAT_SLAB * kSlabBudgetBwd / 2 : ((S == 1 && g.B > 256) ? 2 * kSlabBudgetBwd : kSlabBudgetBwd);
   g.Cc = chunk_channels(g, g.Cwg, T, g.G, NHWC, bbudget);
   g.G = even_groups(g.Cc / 4, g.G);
   T = ((g.P * g.G + 63) / 64) * 64;
