@@ -1,5 +1,5 @@
 #!/usr/bin/env bash
-# Round-3 evidence in one gpurun call (copy what it leaves under gpurun_out/ into profiles/r03_*; DESIGN.md section 5
+# Round-3 evidence in one gpurun call (scripts/collect_round3_profiles.py copies what it leaves under gpurun_out/ into profiles/r03_*; DESIGN.md section 5
 # names the files): rocprofv3 kernel stats of the headline bench, the saturating batch, config 5 and the large maps;
 # FETCH / WRITE_SIZE passes; the forward's PMC counters; the bench lines, incl. `--gpus 2` started by bench.py itself.
 set -u
