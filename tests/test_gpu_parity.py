@@ -385,6 +385,8 @@ def test_vit_tiny_nfp_bf16_k5_l2_step(dev):
     ((2, 960, 7, 7), dict(R=1, measure="norm", p=2, padding=1)),
     ((300, 512, 7, 7), dict(R=1, measure="cosine", padding=1)),       # one workgroup per image: more channels than threads
     ((600, 960, 7, 7), dict(R=1, measure="cosine", padding=1)),       # ... than twice the threads (staged grad(GAP) loop)
+    ((1100, 64, 7, 7), dict(R=1, measure="cosine", padding=1)),       # four workgroups per CU: quarter-size workgroups, both passes
+    ((1040, 64, 14, 14), dict(R=1, measure="norm", p=2, padding=1)),
 ])
 def test_fused_pool_matches_composition(shape, ctor, layout, dtype, dev):
     """nfp_pool (one pass: GAP(x) and GAP(NFP(x)), NFP_Pooling.py:27-31) against the same two reductions composed from
