@@ -568,7 +568,10 @@ __global__ void __launch_bounds__(GEMM ? 1024 : kBwdThreads) bwd_fast(const KP g
   }
   pair_load_to(gq0, oq0, min(t * VP, NO - VP));
   // (DotProduct has no saved norms: the load reads the output map instead — in bounds, unused — rather than sit under a branch)
-  const float nrm = (M == NFP_COSINE) ? (g.unit ? (const float*)out : saved)[(long long)b * P + min(t, P - 1)] : 0.f;
+  // (DotProduct has no saved norms: the load reads the output map instead — in bounds, rather than sit under a branch —
+  // and its bits are masked to 0: read as floats, a bf16 map holds NaN / Inf patterns, and NaN * 0 would reach ipn)
+  const float nrm_raw = (M == NFP_COSINE) ? (g.unit ? (const float*)out : saved)[(long long)b * P + min(t, P - 1)] : 0.f;
+  const float nrm = __int_as_float(__float_as_int(nrm_raw) & (g.unit ? 0 : -1));
   uint4 bo[L_BRQ<R>::v];  // this pixel's window offsets (phase B)
   if constexpr (!GEMM) {
     const uint4* bot = (const uint4*)(ws + L.boff) + (long long)p * L_BRQ<R>::v;
@@ -739,6 +742,18 @@ __global__ void __launch_bounds__(GEMM ? 1024 : kBwdThreads) bwd_fast(const KP g
           Dj += CC[n * P + r];
         }
         wv = 0.f;
+        // diff, a pair whose both ends are r (replicate padding; reflect on tiny maps): distance 0.  L2's coefficient is
+        // 0 there and nothing changes; RMSE's is +-inf (nfp.py:172-179 through torch's sqrt: no subgradient at 0), and
+        // the reference's NaN on that pixel has to come out: +2c on the diagonal, -2c across = inf - inf
+        if (g.diff && M != kNormP1) {   // (p = 1: sign(0) = 0, nothing to add)
+          while (sm) {
+            const int n = __builtin_ctz(sm);
+            sm &= sm - 1;
+            const float c = CC[n * P + r];
+            Dj += 2.f * c;
+            wv -= 2.f * c;
+          }
+        }
       }
     }
     Wt[e] = wv;

@@ -1310,3 +1310,66 @@ def test_workspace_first_seen_inside_a_graph_capture(dev):
     y2 = m(x)                                          # eager: builds the tables now
     assert [k for k in functional._WORKSPACES if k[1:3] == (6, 5)]
     assert rel_err(y.cpu().numpy(), y2.cpu().numpy()) <= 2e-6
+
+
+def _load_script(name):
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location(name, os.path.join(os.path.dirname(__file__), "..", "scripts", name + ".py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_random_stress_of_the_table_kernels_at_large_batches(dev):
+    """Batches of 1024+ images run quarter-size workgroups, four per CU, in both passes (csrc/nfp_hip.hip): random small
+    maps, every hot measure incl. Norm p = 1, padding modes, layouts, storage types, plain and pooled, against the
+    float64 formulation — NaN patterns included.  scripts/stress_big_batch.py is the long form."""
+    import random
+    sb = _load_script("stress_big_batch")
+    rnd = random.Random(4242)
+    for _ in range(24):
+        ok, desc, errs, vs = sb.one_case(rnd, dev)
+        assert ok, (desc, errs, vs)
+        torch.cuda.empty_cache()
+
+
+def test_dot_product_backward_in_bf16_storage_has_no_nan(dev):
+    """Round 3 found it with the stress above: DotProduct keeps no saved norms, so the table backward reads the OUTPUT MAP
+    in their place; read as floats, a bf16 map holds NaN / Inf bit patterns, and `NaN * 0` reached the window weights.
+    (The vector backward: C not a multiple of 32.)"""
+    sb = _load_script("stress_tile")
+    from neighbour_feature_pooling_amd import NFPPooling, _abi
+    from neighbour_feature_pooling_amd._host import nfp_host
+    from neighbour_feature_pooling_amd.synth import feature_map
+    m = NFPPooling(60, R=1, measure="dot", padding=1, padding_mode="zeros")
+    x = torch.from_numpy(feature_map((8, 60, 12, 5), 5)).to(dev).bfloat16().requires_grad_(True)
+    out = m(x)
+    go = torch.from_numpy(feature_map(tuple(out.shape), 6)).to(dev).bfloat16()
+    gx, = torch.autograd.grad(out, x, go)
+    assert _abi.load().nfp_last_variant().decode().startswith("bwd_fast<R1,dot,bf16,nchw")
+    x64 = x.detach().double().requires_grad_(True)
+    gref, = torch.autograd.grad(nfp_host(x64, m.config), x64, go.double())
+    assert not torch.isnan(gx).any()
+    assert sb.rel_err(gx.float().cpu().numpy(), gref.cpu().numpy()) <= 2e-2
+
+
+@pytest.mark.parametrize("mode,R,shape", [("replicate", 1, (5, 32, 13, 16)), ("reflect", 2, (3, 16, 12, 10)), ("replicate", 2, (1030, 8, 6, 7))])
+def test_rmse_has_no_subgradient_at_distance_zero_like_the_reference(mode, R, shape, dev):
+    """RMSE (nfp.py:172-179) of a pixel and its own padded copy — replicate padding; reflect with R = 2, where tap -2 of
+    column 1 lands on column 1 — is sqrt(0): torch's backward gives inf * 0 = NaN on that pixel, every channel.  The table
+    kernels dropped such pairs (right for L2, whose gradient at 0 is 0) and returned numbers where the reference has NaN;
+    they now add the pair's +-inf to both of the pixel's weights.  The NaN pattern and every other element must match."""
+    sb = _load_script("stress_tile")
+    from neighbour_feature_pooling_amd import NFPPooling, _abi
+    from neighbour_feature_pooling_amd._host import nfp_host
+    from neighbour_feature_pooling_amd.synth import feature_map
+    m = NFPPooling(shape[1], R=R, measure="rmse", padding=R, padding_mode=mode)
+    x = torch.from_numpy(feature_map(shape, 21)).to(dev).requires_grad_(True)
+    out = m(x)
+    go = torch.from_numpy(feature_map(tuple(out.shape), 22)).to(dev)
+    gx, = torch.autograd.grad(out, x, go)
+    assert _abi.load().nfp_last_variant().decode().startswith("bwd_fast<")
+    x64 = x.detach().double().requires_grad_(True)
+    gref, = torch.autograd.grad(nfp_host(x64, m.config), x64, go.double())
+    assert torch.isnan(gref).any()
+    assert sb.rel_err(gx.cpu().numpy(), gref.cpu().numpy()) <= 2e-5
