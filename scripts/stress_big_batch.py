@@ -15,11 +15,13 @@ from stress_tile import rel_err
 
 def one_case(rnd, dev):
     R = rnd.choice([1, 1, 2])
-    H, W = rnd.randint(R + 1, 16), rnd.randint(R + 1, 16)
+    hw = int(os.environ.get("STRESS_HW", "16"))
+    H, W = rnd.randint(R + 1, hw), rnd.randint(R + 1, hw)
     if H * W < 4:
         H = W = 3
     C = 4 * rnd.randint(1, 8 if R == 2 else 16)
-    B = rnd.randint(1024, 1400)
+    lo, hi = [int(v) for v in os.environ.get("STRESS_B", "1024,1400").split(",")]   # (STRESS_B=1,70: the same generator at small batches)
+    B = rnd.randint(lo, hi)
     meas = rnd.choice(["cosine", "cosine", "norm", "norm1", "dot", "gfc", "rmse"])
     mode = rnd.choice(["reflect", "zeros", "replicate"])
     cl, bf = rnd.random() < 0.5, rnd.random() < 0.25
