@@ -1373,3 +1373,18 @@ def test_rmse_has_no_subgradient_at_distance_zero_like_the_reference(mode, R, sh
     gref, = torch.autograd.grad(nfp_host(x64, m.config), x64, go.double())
     assert torch.isnan(gref).any()
     assert sb.rel_err(gx.cpu().numpy(), gref.cpu().numpy()) <= 2e-5
+
+
+def test_random_stress_of_the_one_pass_multi_radius_maps(dev):
+    """MultiRadiusNFPPooling (nfp_heads.py:88-110) on random small maps, every hot measure, against the float64
+    cat([NFP_R1(x), NFP_R2(x)]) — scripts/stress_multi_radius.py is the long form (200 cases passed)."""
+    import random
+    sm = _load_script("stress_multi_radius")
+    rnd = random.Random(808)
+    fused = 0
+    for _ in range(24):
+        ok, desc, errs, vs = sm.one_case(rnd, dev)
+        fused += "R1+2" in vs[0]
+        assert ok, (desc, errs, vs)
+        torch.cuda.empty_cache()
+    assert fused >= 6
