@@ -25,7 +25,8 @@ def rel_err(a, b):
 
 def one_case(rnd, dev):
     R = rnd.choice([1, 1, 1, 2])
-    W = rnd.randint(2 * R + 2, 120 if R == 2 else 200)
+    wide = os.environ.get("STRESS_WIDE") == "1"   # (rows beyond the row-band kernels' envelope too: whoever serves them)
+    W = rnd.randint(2 * R + 2, (150 if R == 2 else 270) if wide else (120 if R == 2 else 200))
     H = rnd.randint(max(R + 1, 513 // W + 1), max(R + 2, min(160, 40000 // W)))
     C = 4 * rnd.randint(1, rnd.choice([4, 12, 40]))
     B = rnd.choice([1, 2, 3, 7, 40, 130]) if H * W * C < 400000 else rnd.choice([1, 2, 3])
