@@ -145,7 +145,8 @@ int nfp_backward(const nfp_desc* d, const void* x, const void* grad_out, const v
  * out_map [B,N,Ho,Wo] (dtype of x) is also written: the backward needs it, callers may ignore it.
  * Served only where nfp_pool_supported(d) != 0 — cosine / dot / gfc / L2 / rmse on "same" maps (stride 1, padding = R),
  * NCHW or channels-last, float32 or bf16: maps of at most 512 pixels with the descriptor's workspace set, larger maps
- * with rows of up to about 200 (k = 3) / 120 (k = 5) pixels; the answer is a dry
+ * with rows of W <= 254 (k = 3) / W <= 142 (k = 5) pixels — (W + 2R)(3R + 1) <= 1024, one thread per padded position of
+ * the smallest row band — and any height the descriptor allows (H <= 32767); the answer is a dry
  * run of both launchers, so a 1 means both nfp_pool_forward and nfp_pool_backward will launch.  Otherwise compose
  * nfp_forward with ordinary pooling.
  */

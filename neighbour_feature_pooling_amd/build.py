@@ -50,12 +50,27 @@ def compile_hip(out_lib, extra_flags=(), verbose=False):
     return out_lib
 
 
-def build_hip(force=False, verbose=False):
-    """Compile csrc/*.hip -> libnfp_hip.so.  Returns the library path."""
-    if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= _newest_source_mtime():
-        return LIB
-    compile_hip(LIB + ".tmp", verbose=verbose)
-    os.replace(LIB + ".tmp", LIB)
+# Test build of the same sources with -DNFP_LDS_POISON (csrc/nfp_tile.h::lds_poison): the row-band kernels start on an LDS
+# full of signalling NaNs.  tests/test_gpu_tile.py runs its oracle / golden cases once more on this library.
+LIB_POISON = os.path.join(_HERE, "libnfp_hip_poison.so")
+
+
+def build_hip(force=False, verbose=False, poison=True):
+    """Compile csrc/*.hip -> libnfp_hip.so (and, side by side, the LDS-poison test build).  Returns the library path."""
+    import concurrent.futures as cf
+    newest = _newest_source_mtime()
+    jobs = []
+    if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < newest:
+        jobs.append((LIB, ()))
+    if poison and (force or not os.path.exists(LIB_POISON) or os.path.getmtime(LIB_POISON) < newest):
+        jobs.append((LIB_POISON, ("-DNFP_LDS_POISON",)))
+
+    def one(job):
+        lib, flags = job
+        compile_hip(lib + ".tmp", extra_flags=flags, verbose=verbose)
+        os.replace(lib + ".tmp", lib)
+    with cf.ThreadPoolExecutor(max_workers=2) as ex:
+        list(ex.map(one, jobs))
     return LIB
 
 

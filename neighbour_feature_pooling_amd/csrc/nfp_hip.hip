@@ -56,9 +56,13 @@ int make_kp(const nfp_desc* d, KP* g) {
   g->Wo = (d->W + 2 * d->pad - span) / d->stride + 1;
   g->O = g->Ho * g->Wo;
   g->measure = d->measure; g->similarity = d->similarity != 0; g->diff = d->diff_weights != 0; g->dtype = d->dtype;
+  // EMD (nfp.py:207-216) = -+ sum_c |centre - neighbour|: the pure-neighbour conv output subtracted from the centre by the
+  // measure itself — value and autograd gradient (abs: sign, 0 at 0) are those of Norm p = 1 on the difference weights
+  // (nfp.py:141-148: LA.norm(ord=1) = sum |.|, backward sgn), so every kernel serves it as that
+  if (d->measure == NFP_EMD) { g->measure = NFP_NORM; g->diff = 1; }
   g->godtype = d->dtype;
   g->odtype = d->dtype;
-  g->p = d->p; g->eps = d->eps; g->q_scs = d->q_scs;
+  g->p = d->measure == NFP_EMD ? 1.f : d->p; g->eps = d->eps; g->q_scs = d->q_scs;
   g->sB = d->sxB; g->sC = d->sxC; g->sH = d->sxH; g->sW = d->sxW;
   g->gB = d->sgB != 0 ? d->sgB : d->sxB;
   g->ws = (const unsigned char*)d->ws;
@@ -663,11 +667,12 @@ int forward_impl(const nfp_desc* d, const void* x, void* out, float* saved, void
   if (g.B == 0) return NFP_OK;
   hipStream_t st = (hipStream_t)hip_stream;
   if (g.rs == 12) {
-    if (g.ws == nullptr || !fast_ok(g, x, x) || hot_l1(g))
-      return fail(NFP_E_UNSUPPORTED, "multi-radius: cosine / L2 on maps of at most %d pixels, C %% 4 == 0, dense layout, "
-                  "descriptor with a workspace", kBwdThreads);
-    const int rc = hot_product(g) ? launch_fwd_band<12, NFP_COSINE>(g, x, out, saved, st)
-                                           : launch_fwd_band<12, NFP_NORM>(g, x, out, saved, st);
+    if (g.ws == nullptr || !fast_ok(g, x, x))
+      return fail(NFP_E_UNSUPPORTED, "multi-radius: cosine / dot / gfc / L2 / rmse / norm p=1 / emd on maps of at most %d pixels, "
+                  "C %% 4 == 0, dense layout, descriptor with a workspace", kBwdThreads);
+    const int rc = hot_l1(g) ? launch_fwd_band<12, kNormP1>(g, x, out, saved, st)
+                   : hot_product(g) ? launch_fwd_band<12, NFP_COSINE>(g, x, out, saved, st)
+                                    : launch_fwd_band<12, NFP_NORM>(g, x, out, saved, st);
     return rc == kNotApplicable ? fail(NFP_E_UNSUPPORTED, "multi-radius: the map does not fit the hot-path forward") : rc;
   }
   if (g_sw.tile_first.load(std::memory_order_relaxed))
@@ -742,11 +747,12 @@ int backward_impl(const nfp_desc* d, const void* x, const void* grad_out, const 
   if (g.B == 0) return NFP_OK;
   hipStream_t st = (hipStream_t)hip_stream;
   if (g.rs == 12) {
-    if (g.ws == nullptr || !fast_ok(g, x, grad_x) || hot_l1(g))
-      return fail(NFP_E_UNSUPPORTED, "multi-radius: cosine / L2 on maps of at most %d pixels, C %% 4 == 0, dense layout, "
-                  "descriptor with a workspace", kBwdThreads);
-    const int rc = hot_product(g) ? launch_bwd_vec<12, NFP_COSINE>(g, x, grad_out, out, saved, grad_x, st)
-                                           : launch_bwd_vec<12, NFP_NORM>(g, x, grad_out, out, saved, grad_x, st);
+    if (g.ws == nullptr || !fast_ok(g, x, grad_x))
+      return fail(NFP_E_UNSUPPORTED, "multi-radius: cosine / dot / gfc / L2 / rmse / norm p=1 / emd on maps of at most %d pixels, "
+                  "C %% 4 == 0, dense layout, descriptor with a workspace", kBwdThreads);
+    const int rc = hot_l1(g) ? launch_bwd_vec<12, kNormP1>(g, x, grad_out, out, saved, grad_x, st)
+                   : hot_product(g) ? launch_bwd_vec<12, NFP_COSINE>(g, x, grad_out, out, saved, grad_x, st)
+                                    : launch_bwd_vec<12, NFP_NORM>(g, x, grad_out, out, saved, grad_x, st);
     return rc == kNotApplicable ? fail(NFP_E_UNSUPPORTED, "multi-radius: the map does not fit the hot-path backward") : rc;
   }
   if (g_sw.tile_first.load(std::memory_order_relaxed))
@@ -1021,7 +1027,7 @@ int nfp_pool_forward(const nfp_desc* d, const void* x, float* gap, float* nfpm, 
   KP g;
   if (int rc = make_kp(d, &g)) return rc;
   if (!x || !gap || !nfpm || !out_map) return fail(NFP_E_INVALID, "null tensor pointer");
-  if (!pool_measure_ok(g)) return fail(NFP_E_UNSUPPORTED, "fused pooling tail: cosine / L2 (norm p=2), one radius");
+  if (!pool_measure_ok(g)) return fail(NFP_E_UNSUPPORTED, "fused pooling tail: cosine / dot / gfc / L2 (norm p=2) / rmse, one radius");
   if (g.B == 0) return NFP_OK;
   hipStream_t st = (hipStream_t)hip_stream;
   int rc;
@@ -1039,7 +1045,7 @@ int nfp_pool_backward(const nfp_desc* d, const void* x, const float* grad_gap, c
   KP g;
   if (int rc = make_kp(d, &g)) return rc;
   if (!x || !grad_gap || !grad_nfpm || !out_map || !grad_x) return fail(NFP_E_INVALID, "null tensor pointer");
-  if (!pool_measure_ok(g)) return fail(NFP_E_UNSUPPORTED, "fused pooling tail: cosine / L2 (norm p=2), one radius");
+  if (!pool_measure_ok(g)) return fail(NFP_E_UNSUPPORTED, "fused pooling tail: cosine / dot / gfc / L2 (norm p=2) / rmse, one radius");
   if (stats_of(g.measure) > 0 && !saved) return fail(NFP_E_INVALID, "missing saved state");
   if (g.B == 0) return NFP_OK;
   hipStream_t st = (hipStream_t)hip_stream;

@@ -152,8 +152,9 @@ inline bool hot_product(const KP& g) { return g.measure == NFP_COSINE || g.measu
 inline bool hot_measure(const KP& g) {
   return hot_product(g) || (g.measure == NFP_NORM && g.p == 2.f) || g.measure == NFP_RMSE;
 }
-// Norm p = 1 (the class default, nfp.py:16): instantiations of its own of the table kernels (sums of |a - b|; a gradient
-// in sign(a - b)), plain maps only — no fused pooling tail, no multi-radius, no row-band kernels yet.
+// Norm p = 1 (the class default, nfp.py:16) — and EMD (nfp.py:207-216), the same sum, which make_kp turns into it:
+// instantiations of their own of the table kernels, the radius-(1, 2) form and the row-band kernels (sums of |a - b|; a
+// gradient in sign(a - b)); plain maps only — no fused pooling tail.
 inline bool hot_l1(const KP& g) { return g.measure == NFP_NORM && g.p == 1.f; }
 inline const char* hot_name(const KP& g) {
   if (hot_l1(g)) return "l1";

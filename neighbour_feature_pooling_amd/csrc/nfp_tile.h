@@ -42,12 +42,29 @@ constexpr int kPoolSub = 1;  // fused pooling tail: a band's pixels in this many
 constexpr int kTileKQ = 4;   // channel quads a thread stages per chunk (16 registers): a chunk is 4 * G * kTileKQ channels
 
 struct TileGeo {  // by value in kernarg
-  int nb;         // bands per image: band i owns rows [i H / nb, (i + 1) H / nb) — every band at least R + 1 rows
+  int nb;         // bands per image: H = nb * hq + hr; band i owns hq rows, the first hr bands one more — rows
+                  // [i hq + min(i, hr), (i + 1) hq + min(i + 1, hr)); every band at least R + 1 rows
   int rows;       // padded rows of the largest band = blockDim.z
   int Wu;         // padded row length W + 2R = blockDim.y
   int Ppb;        // slab slots per channel quad (>= rows * Wu; the padding spreads the channel groups over the LDS banks)
   int S;          // backward: channel blocks per (image, band)
+  int hq, hr;     // H / nb, H % nb (host: exact for any H — round 3 divided band * H by nb through a float reciprocal,
+                  // which is exact below 2^21 only: maps of ~5 400 rows and more got wrong band boundaries)
+  int ldsw;       // 32-bit words of dynamic LDS of the launch (the -DNFP_LDS_POISON test build fills them at entry)
 };
+
+// Test build (-DNFP_LDS_POISON, tests/test_gpu_tile.py::test_row_band_kernels_with_poisoned_lds): every word of the
+// workgroup's LDS is a signalling NaN before the kernel proper starts.  The row-band kernels let taps past the padded
+// band read "whatever lies there" because such a value only reaches sums nobody looks up; on a fresh LDS allocation
+// that is usually zeros or a previous workgroup's finite numbers, which would also hide a value that IS looked up.
+__device__ __forceinline__ void lds_poison(void* lds, int words) {
+#ifdef NFP_LDS_POISON
+  uint32_t* w = (uint32_t*)lds;
+  const int nth = blockDim.x * blockDim.y * blockDim.z, tid = threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z);
+  for (int i = tid; i < words; i += nth) w[i] = 0x7FA00000u;
+  __syncthreads();
+#endif
+}
 
 // workgroup id -> (image, item of the image): ids i, i + 8, i + 16, ... share an XCD, so a group of 8 images is dealt one
 // image per XCD and all `per` items (bands x channel blocks) of an image follow each other on it.  Bijective for any B
@@ -67,8 +84,8 @@ template <int R>
 struct TileBand {
   int y0, y1, rows;  // owned rows [y0, y1); padded rows y0 - R .. y1 + R - 1
   __device__ __forceinline__ TileBand(const KP& g, const TileGeo& tg, int band) {
-    y0 = __builtin_amdgcn_readfirstlane(fdivi(band * g.H, tg.nb));
-    y1 = __builtin_amdgcn_readfirstlane(fdivi((band + 1) * g.H, tg.nb));
+    y0 = __builtin_amdgcn_readfirstlane(band * tg.hq + min(band, tg.hr));
+    y1 = __builtin_amdgcn_readfirstlane((band + 1) * tg.hq + min(band + 1, tg.hr));
     rows = y1 - y0 + 2 * R;
   }
 };
@@ -266,6 +283,7 @@ __global__ void __launch_bounds__(1024, (R == 1 ? 8 : 4)) fwd_tile(const KP g, c
   constexpr int N = Win<R>::N, NF = Win<R>::NF;
   constexpr int ES = BF ? 2 : 4;
   extern __shared__ __attribute__((aligned(16))) float4 lds4[];
+  lds_poison(lds4, tg.ldsw);
   int b, band;
   tile_ids(blockIdx.x, g.B, tg.nb, b, band);
   const TileBand<R> bd(g, tg, band);
@@ -350,7 +368,10 @@ __global__ void __launch_bounds__(1024, (R == 1 ? 8 : 4)) fwd_tile(const KP g, c
       for (int cq = ps.gl; cq < ncq; cq += G) {
         const float4* r0 = slab + cq * Ppb + v;
         const float4 a = r0[0];
-        nrm = fmaf(a.x, a.x, fmaf(a.y, a.y, fmaf(a.z, a.z, fmaf(a.w, a.w, nrm))));
+        if (M == kNormP1)   // (Norm p = 1 — the class default, nfp.py:16,141-148 — and EMD, nfp.py:207-216: sums of |.|)
+          nrm += (fabsf(a.x) + fabsf(a.y)) + (fabsf(a.z) + fabsf(a.w));
+        else
+          nrm = fmaf(a.x, a.x, fmaf(a.y, a.y, fmaf(a.z, a.z, fmaf(a.w, a.w, nrm))));
 #pragma unroll
         for (int d = 0; d < NF; ++d) {
           int dy, dx;
@@ -358,6 +379,8 @@ __global__ void __launch_bounds__(1024, (R == 1 ? 8 : 4)) fwd_tile(const KP g, c
           const float4 q = dy == 0 ? r0[dx] : (r0 + dy * Wu - R)[dx + R];   // (row base + compile-time column)
           if (M == NFP_COSINE) {
             acc[d] = fmaf(a.x, q.x, fmaf(a.y, q.y, fmaf(a.z, q.z, fmaf(a.w, q.w, acc[d]))));
+          } else if (M == kNormP1) {
+            acc[d] += (fabsf(a.x - q.x) + fabsf(a.y - q.y)) + (fabsf(a.z - q.z) + fabsf(a.w - q.w));
           } else {
             const float e0 = a.x - q.x, e1 = a.y - q.y, e2 = a.z - q.z, e3 = a.w - q.w;
             acc[d] = fmaf(e0, e0, fmaf(e1, e1, fmaf(e2, e2, fmaf(e3, e3, acc[d]))));
@@ -412,6 +435,8 @@ __global__ void __launch_bounds__(1024, (R == 1 ? 8 : 4)) fwd_tile(const KP g, c
       if (M == NFP_COSINE) {
         const float s = GFC ? pairv * __builtin_amdgcn_rcpf(fmaf(Fp, fq, g.eps)) : pairv * Fp * fq;
         val = fin_prod(g, s);
+      } else if (M == kNormP1) {
+        val = g.osa * (g.diff ? pairv : fq);     // (no root: the sum of |.| is the norm)
       } else {
         val = fin_dist(g, g.diff ? pairv : fq);  // 'Norm' quirk (nfp.py:74 vs 85): |neighbour|
       }
@@ -501,6 +526,7 @@ __global__ void __launch_bounds__(1024, (R == 1 ? (CST ? 5 : 8) : 4)) bwd_tile(c
   constexpr int N = Win<R>::N, K = Win<R>::K, K2 = Win<R>::K2;
   constexpr int ES = BF ? 2 : 4;
   extern __shared__ __attribute__((aligned(16))) float4 lds4[];
+  lds_poison(lds4, tg.ldsw);
   int b, item;
   tile_ids(blockIdx.x, g.B, tg.nb * tg.S, b, item);
   const int band = item / tg.S, cblk = item - band * tg.S;
@@ -557,7 +583,7 @@ __global__ void __launch_bounds__(1024, (R == 1 ? (CST ? 5 : 8) : 4)) bwd_tile(c
         e = ea + n * P + (((N - 1 - 2 * n) * P + dy * W + dx) & rm);
         e = (rbad[dy + R] || cbad[dx + R]) ? Oob<BF>::e : e;
       }
-      sv[n] = load_1<BF>(outb, e, 0);
+      sv[n] = M == kNormP1 ? 0.f : load_1<BF>(outb, e, 0);   // (p = 1: the gradient does not depend on the distance)
       gov[n] = POOL ? 0.f : load_1<BF>(gob, ep, n * P);
     }
     float nrm = 0.f;
@@ -576,6 +602,8 @@ __global__ void __launch_bounds__(1024, (R == 1 ? (CST ? 5 : 8) : 4)) bwd_tile(c
       if (M == NFP_COSINE) {
         sv[n] = fmaf(sa, sv[n], sb);
         w[j] = sa * gc;
+      } else if (M == kNormP1) {
+        w[j] = ps.real ? g.osa * gc : 0.f;   // (p = 1: d out / d (a - b)[c] = +-g sign(a - b)[c]; the map itself is not needed)
       } else {
         w[j] = ps.real ? dist_coef(g, gc, sv[n]) : 0.f;
       }
@@ -620,6 +648,13 @@ __global__ void __launch_bounds__(1024, (R == 1 ? (CST ? 5 : 8) : 4)) bwd_tile(c
         D = fmaf(S, sv[n], D);
         w[j] = ipr * ipq * S;
       }
+    } else if (M == kNormP1) {
+      // p = 1: grad_x[c][r] = sum_j w[j] sign(x_r - x_{r + d_j})[c] with the difference weights — a zero-padded tap is a
+      // zero vector in the slab, so sign(x_r - 0) needs no case of its own, and there is no diagonal; with the 'Norm'
+      // quirk a pair pulls on its NEIGHBOUR alone: D sign(x_r)[c], on the centre slot (phase B)
+      const float c1 = w[j];
+      D += (1.f + dneg) * c2;
+      w[j] = -dneg * (c1 + c2);
     } else {
       const float c1 = w[j];
       D += fmaf(-dneg, c1, c2);  // 'Norm' quirk (nfp.py:74 vs 85): only the pair's NEIGHBOUR is pulled
@@ -705,6 +740,19 @@ __global__ void __launch_bounds__(1024, (R == 1 ? (CST ? 5 : 8) : 4)) bwd_tile(c
       if constexpr (POOL) {
         const float4 gg = *(const float4*)(ggap + (long long)b * g.C + c0 + 4 * cq);
         r4 = make_float4(gg.x * g.invP, gg.y * g.invP, gg.z * g.invP, gg.w * g.invP);
+      }
+      if constexpr (M == kNormP1) {
+        const float4 a = (rc + 0 * Wu)[R];
+#pragma unroll
+        for (int j = 0; j < K2; ++j) {
+          const float4 q = (rc + (j / K - R) * Wu)[j % K];
+          const bool c = j == K2 / 2;
+          r4.x = fmaf(w[j], sgn3(c ? a.x : a.x - q.x), r4.x);
+          r4.y = fmaf(w[j], sgn3(c ? a.y : a.y - q.y), r4.y);
+          r4.z = fmaf(w[j], sgn3(c ? a.z : a.z - q.z), r4.z);
+          r4.w = fmaf(w[j], sgn3(c ? a.w : a.w - q.w), r4.w);
+        }
+        return r4;
       }
 #pragma unroll
       for (int j = 0; j < K2; ++j) {

@@ -35,7 +35,7 @@ bool tile_geometry(const KP& g) {
 
 bool tile_ok(const KP& g, const void* x, const void* gx) {
   if (force_generic() || !tile_geometry(g) || (g.C & 3)) return false;
-  if (!hot_measure(g)) return false;
+  if (!hot_measure(g) && !hot_l1(g)) return false;
   const bool nhwc = g.sC == 1 && g.sW == g.C && g.sH == (long long)g.W * g.C;
   if (!g.contig && !nhwc) return false;
   const int es = g.dtype == NFP_F32 ? 4 : 2;
@@ -106,7 +106,7 @@ int launch_fwd_tile_t(KP g, const void* x, void* out, float* saved, hipStream_t 
         g.Cc = 4 << g.Tc;
       }
       const size_t lds = std::max((size_t)(g.Cc / 4) * ppb * 16, vmb) + tail;
-      nfp::TileGeo tg = {nb, rows, Wu, ppb, 1};
+      nfp::TileGeo tg = {nb, rows, Wu, ppb, 1, g.H / nb, g.H % nb, (int)(lds / 4)};
       if (nb_out) *nb_out = POOL ? nb * nfp::kPoolSub : nb;   // (pooled: rows of partial sums per image)
       snprintf(g_variant, sizeof(g_variant), "fwd_tile<R%d,%s,%s,%s%s>x%d", R, hot_name(g), BF ? "bf16" : "f32",
                NHWC ? "nhwc" : "nchw", POOL ? ",pool" : "", nb);
@@ -173,7 +173,7 @@ int launch_bwd_tile_t(KP g, const void* x, const void* go, const void* out, cons
         g.Cc = 4 << g.Tc;
       }
       const size_t lds = fixed + std::max(pv, (size_t)(g.Cc / 4) * ppb * 16 + wr);
-      nfp::TileGeo tg = {nb, rows, Wu, ppb, S};
+      nfp::TileGeo tg = {nb, rows, Wu, ppb, S, g.H / nb, g.H % nb, (int)(lds / 4)};
       const dim3 block(G, Wu, rows);
       // dense grad_x stores through LDS (nfp_tile.h, phase B): channels-last with one thread per position, pixels of 256
       // bytes and more (below, the scattered 16-byte stores of a pixel complete their cache lines soon enough: measured
@@ -243,6 +243,10 @@ int bwd_rm(const KP& g, const void* x, const void* go, const void* out, const fl
 int tile_forward(const KP& g, const void* x, void* out, float* saved, hipStream_t st, bool pool, float* part, int* nb) {
   if (!tile_ok(g, x, x)) return kNotApplicable;
   const bool cosv = hot_product(g);
+  if (hot_l1(g)) {   // Norm p = 1 (the class default, nfp.py:16) and EMD (make_kp): plain maps
+    if (pool) return kNotApplicable;
+    return g.R == 1 ? fwd_rm<1, kNormP1, false>(g, x, out, saved, st, part, nb) : fwd_rm<2, kNormP1, false>(g, x, out, saved, st, part, nb);
+  }
   if (pool) {
     if (cosv) return g.R == 1 ? fwd_rm<1, NFP_COSINE, true>(g, x, out, saved, st, part, nb) : fwd_rm<2, NFP_COSINE, true>(g, x, out, saved, st, part, nb);
     return g.R == 1 ? fwd_rm<1, NFP_NORM, true>(g, x, out, saved, st, part, nb) : fwd_rm<2, NFP_NORM, true>(g, x, out, saved, st, part, nb);
@@ -255,6 +259,11 @@ int tile_backward(const KP& g, const void* x, const void* go, const void* out, c
                   bool pool, const float* ggap, const float* gnfpm) {
   if (!tile_ok(g, x, gx)) return kNotApplicable;
   const bool cosv = hot_product(g);
+  if (hot_l1(g)) {
+    if (pool) return kNotApplicable;
+    return g.R == 1 ? bwd_rm<1, kNormP1, false>(g, x, go, out, saved, gx, st, ggap, gnfpm)
+                    : bwd_rm<2, kNormP1, false>(g, x, go, out, saved, gx, st, ggap, gnfpm);
+  }
   if (pool) {
     if (cosv) return g.R == 1 ? bwd_rm<1, NFP_COSINE, true>(g, x, go, out, saved, gx, st, ggap, gnfpm) : bwd_rm<2, NFP_COSINE, true>(g, x, go, out, saved, gx, st, ggap, gnfpm);
     return g.R == 1 ? bwd_rm<1, NFP_NORM, true>(g, x, go, out, saved, gx, st, ggap, gnfpm) : bwd_rm<2, NFP_NORM, true>(g, x, go, out, saved, gx, st, ggap, gnfpm);

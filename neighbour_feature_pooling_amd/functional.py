@@ -141,15 +141,37 @@ def output_shape(d):
     return d.B, n.value, ho.value, wo.value
 
 
-_WORKSPACES = {}            # (device, geometry) -> [uint8 tensor, fill event or None]: the descriptor's constant tables
+_WORKSPACES = {}            # (device, geometry) -> [uint8 tensor, fill event or None, fill stream, device index] or False
+_PENDING_FILLS = []         # the records of _WORKSPACES whose fill event has not been seen complete yet
+
+
+def _order_after_fills(device):
+    """Every launch path calls this while a table fill may still be running (the ordering used to live in
+    _workspace(), which a plan-cache hit never reaches — a same-shape call on ANOTHER stream right after the first one
+    launched on tables that were not written yet).  A fill is ordered before later work of its own stream; any other
+    stream waits for its event on the device (no host synchronisation); a completed event is dropped, so in steady state
+    this is one truthiness test of an empty list.  Under a graph capture neither an event query nor a wait on an event
+    recorded outside the capture is legal: nothing is done — a capture is preceded by a device synchronisation
+    (torch.cuda.graph does one itself), which also completes every fill enqueued before it."""
+    if torch.cuda.is_current_stream_capturing():
+        return
+    cur = None
+    for rec in list(_PENDING_FILLS):
+        if rec[1] is None or rec[1].query():
+            rec[1] = None
+            _PENDING_FILLS.remove(rec)
+        elif rec[3] == device.index:
+            if cur is None:
+                cur = _raw_stream(device)
+            if cur != rec[2]:
+                torch.cuda.current_stream(device).wait_event(rec[1])
 
 
 def _workspace(d, device):
     """Device pointer of the constant tables of `d` (include/nfp.h: nfp_workspace_bytes / nfp_workspace_init), or
     None.  They depend on the geometry only, so every call with the same map size and kernel shares one buffer per
-    device.  The fill kernel is enqueued once, on the stream that first needs the tables, followed by an event; a later
-    call on ANOTHER stream makes that stream wait for the event (no host synchronisation), and once the event has
-    completed it is dropped.  Under a graph capture no table is built (the fill would only be recorded, not run, and a
+    device.  The fill kernel is enqueued once, on the stream that first needs the tables, followed by an event
+    (_order_after_fills).  Under a graph capture no table is built (the fill would only be recorded, not run, and a
     later eager call would read an unfilled buffer): that one call is planned without tables and nothing is cached —
     warm a geometry up before capturing it, as every graph user does anyway."""
     key = (device.index, d.H, d.W, d.R, d.pad, d.stride, d.dilation, d.pad_mode, d.inner_R)
@@ -172,15 +194,10 @@ def _workspace(d, device):
                 _abi.check(L.nfp_workspace_init(ctypes.byref(d), ws.data_ptr(), _raw_stream(device)))
                 ev = torch.cuda.Event()
                 ev.record(torch.cuda.current_stream(device))
-            _WORKSPACES[key] = rec = [ws, ev, _raw_stream(device)]
+            _WORKSPACES[key] = rec = [ws, ev, _raw_stream(device), device.index]
+            _PENDING_FILLS.append(rec)
     if rec is False:
         return None
-    if rec[1] is not None:
-        # the fill is ordered before later work of its own stream; any other stream waits for it on the device
-        if rec[1].query():
-            rec[1] = None
-        elif _raw_stream(device) != rec[2]:
-            torch.cuda.current_stream(device).wait_event(rec[1])
     return rec[0].data_ptr()
 
 
@@ -210,11 +227,14 @@ def _plan(x, layout, cfg):
     loss.backward()."""
     key = (tuple(x.shape), x.stride(0), layout, x.dtype, cfg, x.device.index)
     plan = _plans_get(key)
+    if _PENDING_FILLS:
+        _order_after_fills(x.device)
     if plan is None:
         L = _abi.load()
         d = make_desc(x, cfg, layout)
         d.ws = _workspace(d, x.device)
         cacheable = d.ws is not None or not torch.cuda.is_current_stream_capturing()
+        d.cacheable = cacheable     # (a Python attribute of the ctypes object: the pooled-tail caches below ask)
         buf = ctypes.create_string_buffer(1024)
         rc = L.nfp_plan(ctypes.byref(d), 1, buf, len(buf))
         no_bwd = None if rc == 0 else L.nfp_last_error().decode()
@@ -343,13 +363,14 @@ def _pool_saved_floats(x, layout, cfg, d):
     ns = _plans_get(key)
     if ns is None:
         ns = int(_abi.load().nfp_pool_saved_floats(ctypes.byref(d)))
-        _plans_put(key, ns)
+        if getattr(d, "cacheable", True):   # (a table-less plan made under a graph capture says nothing about later calls)
+            _plans_put(key, ns)
     return ns
 
 
 def nfp_pool_fused_ok(x, cfg):
     """True when the fused GAP + pooled-NFP kernels can serve this call: "same" maps (stride 1, pad = R; above 512 pixels:
-    rows of up to about 200 / 120 pixels for k = 3 / 5), cosine / dot / gfc / L2 / rmse, float32 or bfloat16, images dense in NCHW
+    rows of W <= 254 / 142 pixels for k = 3 / 5, any height), cosine / dot / gfc / L2 / rmse, float32 or bfloat16, images dense in NCHW
     or channels-last order.  (The library answers: a dry run of both launchers.)"""
     if not (x.is_cuda and x.dim() == 4 and x.dtype in _DTYPES):
         return False
@@ -361,8 +382,10 @@ def nfp_pool_fused_ok(x, cfg):
     key = ("pool", tuple(x.shape), x.stride(0), layout, x.dtype, cfg, x.device.index)
     ok = _plans_get(key)
     if ok is None:
-        ok = bool(_abi.load().nfp_pool_supported(ctypes.byref(_plan(x, layout, cfg)[0])))
-        _plans_put(key, ok)
+        d = _plan(x, layout, cfg)[0]
+        ok = bool(_abi.load().nfp_pool_supported(ctypes.byref(d)))
+        if getattr(d, "cacheable", True):
+            _plans_put(key, ok)
     return ok
 
 
@@ -415,7 +438,7 @@ def nfp_multi_radius(x, cfg1, cfg2):
     import dataclasses
     fusable = (x.is_cuda and x.dim() == 4 and cfg1.R == 1 and cfg2.R == 2 and cfg1.padding == 1 and cfg2.padding == 2
                and dataclasses.replace(cfg1, R=2, padding=2) == cfg2 and cfg2.inner_R == 0
-               and cfg2.measure in ("cosine", "norm"))
+               and cfg2.measure in ("cosine", "norm", "dot", "gfc", "rmse", "emd"))   # (norm: p = 1 or 2; else refused below)
     if fusable:
         try:
             return nfp(x, dataclasses.replace(cfg2, inner_R=1))

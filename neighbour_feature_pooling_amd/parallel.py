@@ -64,14 +64,18 @@ def max_over_ranks(value, device=None):
 # ---- one process per GPU, started by the program itself --------------------------------------------------------
 # `python bench.py --gpus N` (and `python -m neighbour_feature_pooling_amd.train --gpus N`) must run N ranks with no
 # launcher on the command line.  The parent starts `python -m torch.distributed.run` as a CHILD process and relays its
-# exit code; it never touches the GPU itself (importing torch does not initialise it, and neither does
-# torch.cuda.device_count() on this image), and nothing is exec'ed from a process that has.
+# exit code; it never launches GPU work itself (importing torch does not initialise the GPU; torch.cuda.device_count()
+# counts through amdsmi on this image and does not either — on an image without that path it would call
+# hipGetDeviceCount in the parent, which is still no exec from a process that has), and nothing is exec'ed.
 
 def launched_by_torchrun():
     return "WORLD_SIZE" in os.environ and "RANK" in os.environ
 
 
 def free_port():
+    """A port that was free a moment ago.  (Closed again before torch.distributed.run binds it: two launches started
+    at the same instant on one node can draw the same port — the loser fails at rendezvous, loudly, and is re-run.  The
+    driver's own launcher passes --master-port itself.)"""
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         return s.getsockname()[1]

@@ -84,6 +84,8 @@ def main():
                                               argv, backend=a.backend or ("gloo" if a.cpu else "nccl"),
                                               dry_run=a.print_launch))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if parallel.launched_by_torchrun() and a.gpus != 1 and a.gpus != world:   # (as bench.py: ADVICE r3)
+        raise SystemExit(f"--gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks")
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     backend = a.backend or ("gloo" if a.cpu else "nccl")

@@ -11,6 +11,16 @@ for p in (ROOT, GOLDEN):
         sys.path.insert(0, p)
 
 
+# NFP_TEST_LIB=<file in the package directory>: run the suite on another build of the same sources (the LDS-poison test
+# build, tests/test_gpu_tile.py::test_row_band_kernels_with_poisoned_lds).  The C++ autograd nodes link the product
+# library, so the Python nodes serve (they call whatever _abi loads).
+if os.environ.get("NFP_TEST_LIB"):
+    os.environ["NFP_PY_NODES"] = "1"
+    from neighbour_feature_pooling_amd import _abi as _abi_for_test_lib
+    _abi_for_test_lib.LIB_PATH = os.path.join(ROOT, "neighbour_feature_pooling_amd", os.environ["NFP_TEST_LIB"])
+    assert os.path.exists(_abi_for_test_lib.LIB_PATH), _abi_for_test_lib.LIB_PATH
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

@@ -88,6 +88,49 @@ CASES.append(case("m_scs_p2", (3, 6, 4, 4), dict(R=1, measure="scs", p=2, paddin
 CASES.append(case("m_scs_p1_dissim", (2, 6, 4, 4), dict(R=1, measure="sharpened_cosine", p=1, padding=1,
                                                        similarity=False), 161))
 
+# --- round 4: the row-band kernels (csrc/nfp_tile.h, maps above 512 pixels) in front of the reference ----------------------
+# RESNET18_NFP_AT_LAYER's maps (models/resnet18.py:410-468: layer1 64 x 56 x 56, layer2 128 x 28 x 28), k = 5 L2 on the
+# largest MultiStage map, the other padding modes, the other measures the row-band kernels serve, and the class default
+# (Norm p = 1, nfp.py:16) / EMD on a large map.
+CASES += [
+    case("rn_cos_56x56x64", (2, 64, 56, 56), COS, 70, kind="relu", full_limit=16384),
+    case("rn_cos_28x28x128", (2, 128, 28, 28), COS, 71, kind="relu", full_limit=16384),
+    case("tile_l2_k5_112x112x16", (1, 16, 112, 112), L2K5, 72, full_limit=16384),
+    case("tile_cos_k5_40x40x24", (2, 24, 40, 40), dict(R=2, measure="cosine", padding=2), 73, full_limit=16384),
+    case("tile_cos_zeros_56x56x24", (2, 24, 56, 56), dict(R=1, measure="cosine", padding=1, padding_mode="zeros"), 74,
+         full_limit=16384),
+    case("tile_cos_replicate_56x56x24", (2, 24, 56, 56), dict(R=1, measure="cosine", padding=1, padding_mode="replicate"),
+         75, full_limit=16384),
+    case("tile_l2_replicate_k5_30x37x8", (1, 8, 30, 37), dict(R=2, measure="norm", p=2, padding=2, padding_mode="replicate"),
+         76, full_limit=16384),
+    case("tile_rmse_40x40x16", (2, 16, 40, 40), dict(R=1, measure="rmse", padding=1), 77, full_limit=16384),
+    case("tile_gfc_40x40x16", (2, 16, 40, 40), dict(R=1, measure="gfc", padding=1), 78, full_limit=16384),
+    case("tile_dot_40x40x16", (2, 16, 40, 40), dict(R=1, measure="dot", padding=1), 79, full_limit=16384),
+    case("tile_norm_p1_40x40x16", (2, 16, 40, 40), dict(R=1, measure="norm", padding=1), 80, full_limit=16384),
+    case("tile_norm_p1_k5_zeros_30x37x8", (1, 8, 30, 37), dict(R=2, measure="norm", padding=2, padding_mode="zeros"), 81,
+         full_limit=16384),
+    case("tile_emd_dissim_40x40x16", (2, 16, 40, 40), dict(R=1, measure="emd", padding=1, similarity=False), 82,
+         full_limit=16384),
+    case("tile_norm_p1_quirk_40x40x8", (1, 8, 40, 40), dict(R=1, measure="Norm", padding=1), 83, full_limit=16384),
+]
+
+# --- pooled NFP: adaptive_avg_pool2d(NFPPooling(feat), 1) and its input gradient, what MobileNetV3_MultiStageNFP /
+# MidNFP consume (models/texture_pooling.py:251-252, 320-321).  Fixture: "nfpm" [B,N] and grad_x (sampled) for the
+# output gradient make_pool_grad gives.
+POOL_CASES = [
+    case("pool_ms_cos_112x112x16", (1, 16, 112, 112), COS, 90, kind="relu", full_limit=16384),
+    case("pool_ms_cos_56x56x24", (2, 24, 56, 56), COS, 91, kind="relu", full_limit=16384),
+    case("pool_ms_cos_14x14x112", (2, 112, 14, 14), COS, 92, kind="relu", full_limit=16384),
+    case("pool_l2_k5_28x28x40", (2, 40, 28, 28), L2K5, 93, full_limit=16384),
+]
+POOL_BY_NAME = {c["name"]: c for c in POOL_CASES}
+
+
+def make_pool_grad(c, n_maps):
+    from neighbour_feature_pooling_amd.synth import feature_map
+    return feature_map((c["shape"][0], n_maps), c["seed"] + 2000, "normal")
+
+
 BY_NAME = {c["name"]: c for c in CASES}
 assert len(BY_NAME) == len(CASES)
 

@@ -1312,6 +1312,32 @@ def test_workspace_first_seen_inside_a_graph_capture(dev):
     assert rel_err(y.cpu().numpy(), y2.cpu().numpy()) <= 2e-6
 
 
+def test_workspace_fill_is_ordered_before_a_plan_cache_hit_on_another_stream(dev):
+    """the first call of a geometry enqueues its table fill on stream A; a same-shape call on stream B hits
+    the plan cache — and used to launch without waiting for the fill.  Stream A is held up by a long sleep kernel in
+    front of the fill, so an unordered B would read unwritten tables."""
+    from neighbour_feature_pooling_amd import NFPPooling, functional
+    m = NFPPooling(8, R=1, measure="cosine", padding=1)
+    x = torch.randn(2, 8, 9, 11, device=dev)
+    for k in [k for k in functional._WORKSPACES if k[1:3] == (9, 11)]:
+        del functional._WORKSPACES[k]
+    for k in [k for k in functional._PLANS if isinstance(k[0], tuple) and k[0][2:] == (9, 11)]:
+        del functional._PLANS[k]
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Stream(), torch.cuda.Stream()
+    with torch.cuda.stream(a):
+        torch.cuda._sleep(400_000_000)       # ~0.2 s in front of the fill
+        ya = m(x)
+    with torch.cuda.stream(b):
+        yb = m(x)                            # plan-cache hit, tables possibly still unwritten
+    torch.cuda.synchronize()
+    assert functional._PENDING_FILLS == [] or all(r[1] is not None for r in functional._PENDING_FILLS)
+    yc = m(x)
+    torch.cuda.synchronize()
+    assert functional._PENDING_FILLS == []
+    assert torch.equal(ya, yc) and torch.equal(yb, yc)
+
+
 def _load_script(name):
     import importlib.util, os
     spec = importlib.util.spec_from_file_location(name, os.path.join(os.path.dirname(__file__), "..", "scripts", name + ".py"))

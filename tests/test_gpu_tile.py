@@ -1,6 +1,8 @@
-"""The row-band kernels for maps above 512 pixels (csrc/nfp_tile.h: fwd_tile / bwd_tile) against the float64
-formulation of nfp.py:141-159 on the same inputs, every padding mode / radius / layout / storage type, with the
-dispatcher's choice asserted (these shapes must not fall to the any-geometry kernels)."""
+"""The row-band kernels for maps above 512 pixels (csrc/nfp_tile.h: fwd_tile / bwd_tile) against the ORACLE
+(oracle/nfp_oracle.c, pinned to the reference by tests/golden) on the same inputs — every padding mode / radius / layout /
+storage type, plain and pooled — with the dispatcher's choice asserted (these shapes must not fall to the any-geometry
+kernels).  Round 3 refereed these cases with the package's own float64 torch formulation (_host.nfp_host); since round 4
+that one only referees the random stress (an index-error net, not parity)."""
 import numpy as np
 import pytest
 import torch
@@ -26,13 +28,20 @@ def _cases():
     return cs
 
 
-def _run(B, C, H, W, R, meas, mode, dev, dtype=torch.float32, channels_last=False, similarity=True):
+def _oracle():
+    import oracle
+    oracle.build()
+    return oracle
+
+
+def _run(B, C, H, W, R, meas, mode, dev, dtype=torch.float32, channels_last=False, similarity=True, p=2):
+    """(out, grad_x) of the HIP path and of the oracle on the same inputs (bf16: the same ROUNDED inputs), plus the two
+    kernel variants that ran."""
     from neighbour_feature_pooling_amd import NFPPooling, _abi
-    from neighbour_feature_pooling_amd._host import nfp_host
     from neighbour_feature_pooling_amd.synth import feature_map
     ctor = dict(R=R, measure=meas, padding=R, padding_mode=mode, similarity=similarity)
-    if meas == "norm":
-        ctor["p"] = 2
+    if meas.lower() == "norm":
+        ctor["p"] = p
     m = NFPPooling(C, **ctor)
     x = torch.from_numpy(feature_map((B, C, H, W), 5 * H + W + C)).to(dev).to(dtype)
     if channels_last:
@@ -48,15 +57,17 @@ def _run(B, C, H, W, R, meas, mode, dev, dtype=torch.float32, channels_last=Fals
     gx2, = torch.autograd.grad(out, x, go)
     out2 = m(x)
     assert torch.equal(gx, gx2) and torch.equal(out, out2), "not bitwise reproducible"
-    x64 = x.detach().double().contiguous().requires_grad_(True)
-    ref = nfp_host(x64, m.config)
-    gref, = torch.autograd.grad(ref, x64, go.double())
-    return out.detach(), gx, ref.detach(), gref, fv, bv
+    orc = _oracle()
+    xh = x.detach().float().contiguous().cpu().numpy()      # (bf16: what the kernel read, as float32 — exact)
+    goh = go.float().cpu().numpy()
+    ref = torch.from_numpy(orc.forward(xh, **ctor))
+    gref = torch.from_numpy(orc.backward(xh, goh, **ctor))
+    return out.detach(), gx, ref, gref, fv, bv
 
 
 @pytest.mark.parametrize("B,C,H,W,R,meas,mode", _cases())
 @pytest.mark.parametrize("channels_last", [False, True])
-def test_tile_kernels_match_float64_formulation(B, C, H, W, R, meas, mode, channels_last):
+def test_tile_kernels_match_the_oracle(B, C, H, W, R, meas, mode, channels_last):
     dev = torch.device("cuda:0")
     out, gx, ref, gref, fv, bv = _run(B, C, H, W, R, meas, mode, dev, channels_last=channels_last)
     assert fv.startswith("fwd_tile<") and bv.startswith("bwd_tile<"), (fv, bv)
@@ -72,7 +83,7 @@ def test_tile_kernels_match_float64_formulation(B, C, H, W, R, meas, mode, chann
                                                    (2, 128, 28, 28, 1, "cosine", "zeros")])
 @pytest.mark.parametrize("channels_last", [False, True])
 def test_tile_kernels_bf16_storage(B, C, H, W, R, meas, mode, channels_last):
-    """bf16 load / store, f32 arithmetic: against the float64 formulation on the SAME bf16-rounded inputs."""
+    """bf16 load / store, f32 arithmetic: against the oracle on the SAME bf16-rounded inputs."""
     dev = torch.device("cuda:0")
     out, gx, ref, gref, fv, bv = _run(B, C, H, W, R, meas, mode, dev, dtype=torch.bfloat16, channels_last=channels_last)
     assert fv.startswith("fwd_tile<") and "bf16" in fv and bv.startswith("bwd_tile<"), (fv, bv)
@@ -98,6 +109,78 @@ def test_tile_kernels_one_thread_per_position_on_a_full_chip(B, C, H, W, R, meas
     to, tg = (TOL, TOL) if dtype == torch.float32 else (1e-2, 2e-2)
     assert rel_err(out.float().cpu().numpy(), ref.cpu().numpy()) <= to, fv
     assert rel_err(gx.float().cpu().numpy(), gref.cpu().numpy()) <= tg, bv
+
+
+ROW_BAND_GOLDENS = ["ms_cos_112x112x16", "ms_cos_56x56x24", "ms_cos_28x28x40", "rn_cos_56x56x64", "rn_cos_28x28x128",
+                    "tile_l2_k5_112x112x16", "tile_cos_k5_40x40x24", "tile_cos_zeros_56x56x24", "tile_cos_replicate_56x56x24",
+                    "tile_l2_replicate_k5_30x37x8", "tile_rmse_40x40x16", "tile_gfc_40x40x16", "tile_dot_40x40x16"]
+
+
+@pytest.mark.parametrize("name", ROW_BAND_GOLDENS)
+@pytest.mark.parametrize("channels_last", [False, True])
+def test_row_band_kernels_match_reference_golden(name, channels_last):
+    """The real reference's outputs and input gradients (tests/golden, make_golden.py) on maps the row-band kernels
+    serve — the MultiStage and RESNET18_NFP_AT_LAYER maps, k = 5, the three padding modes, rmse / gfc / dot — with the
+    VARIANT asserted: VERDICT r3 found that the golden test of these maps did not check which kernels had run."""
+    import cases as K
+    from conftest import assert_matches_golden, load_golden
+    from neighbour_feature_pooling_amd import NFPPooling, _abi
+    dev = torch.device("cuda:0")
+    c = K.BY_NAME[name]
+    x = torch.from_numpy(K.make_input(c)).to(dev)
+    if channels_last:
+        x = x.contiguous(memory_format=torch.channels_last)
+    x.requires_grad_(True)
+    m = NFPPooling(c["shape"][1], **c["ctor"])
+    L = _abi.load()
+    out = m(x)
+    fv = L.nfp_last_variant().decode()
+    gx, = torch.autograd.grad(out, x, torch.from_numpy(K.make_grad_out(c, tuple(out.shape))).to(dev))
+    torch.cuda.synchronize()
+    bv = L.nfp_last_variant().decode()
+    assert fv.startswith("fwd_tile<") and bv.startswith("bwd_tile<"), (fv, bv)
+    assert_matches_golden(out.detach().cpu().numpy(), gx.cpu().numpy(), load_golden(name), TOL, 2 * TOL)
+
+
+def test_row_band_kernels_with_poisoned_lds():
+    """the row-band kernels let taps past the padded band read "whatever lies there" on the argument
+    that nobody looks such a value up.  The -DNFP_LDS_POISON build (libnfp_hip_poison.so, build.py) fills every word of a
+    workgroup's LDS with a signalling NaN before the kernel proper starts; the oracle / golden / bf16 / full-chip / pooled
+    cases of this file run once more on it, in one child process (NaN patterns are compared by every one of them)."""
+    import os, subprocess, sys
+    if os.environ.get("NFP_TEST_LIB"):
+        pytest.skip("this IS the run on the test build")
+    env = dict(os.environ, NFP_TEST_LIB="libnfp_hip_poison.so")
+    sel = ("match_the_oracle or reference_golden or bf16_storage or full_chip or fused_pooling_tail_on_large_maps "
+           "or dissimilarity or tall_map or pooled_nfp")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-m", "gpu", "-k", sel,
+                        "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=2400)
+    tail = r.stdout[-3000:] + r.stderr[-1000:]
+    assert r.returncode == 0, tail
+    assert " passed" in r.stdout and "failed" not in r.stdout, tail
+
+
+def test_the_poison_build_is_what_the_child_run_loads():
+    import os
+    from neighbour_feature_pooling_amd import _abi
+    if os.environ.get("NFP_TEST_LIB"):
+        assert _abi.LIB_PATH.endswith(os.environ["NFP_TEST_LIB"])
+        _abi.load()
+    else:
+        assert _abi.LIB_PATH.endswith("libnfp_hip.so")
+
+
+def test_tall_map_band_boundaries_are_exact():
+    """band row ranges came from a float reciprocal that is exact below 2^21 only — [2,4,21651,52] (3609
+    bands) lost its last image row, other heights shifted a boundary by one.  Now H = nb * q + r on the host."""
+    dev = torch.device("cuda:0")
+    for (B, C, H, W, R, meas) in [(2, 4, 21651, 52, 1, "cosine"), (1, 4, 7411, 40, 2, "norm")]:
+        out, gx, ref, gref, fv, bv = _run(B, C, H, W, R, meas, "reflect", dev)
+        assert fv.startswith("fwd_tile<") and bv.startswith("bwd_tile<"), (fv, bv)
+        assert rel_err(out.cpu().numpy(), ref.numpy()) <= TOL, fv
+        assert rel_err(gx.cpu().numpy(), gref.numpy()) <= TOL, bv
+        assert rel_err(out[:, :, -3:].cpu().numpy(), ref[:, :, -3:].numpy()) <= TOL      # the last rows themselves
+        assert rel_err(gx[:, :, -3:].cpu().numpy(), gref[:, :, -3:].numpy()) <= TOL
 
 
 def test_random_geometry_stress_of_the_row_band_kernels():
@@ -161,19 +244,9 @@ def test_tile_kernels_dissimilarity_and_norm_quirk():
     assert fv.startswith("fwd_tile<")
     assert rel_err(out.cpu().numpy(), ref.cpu().numpy()) <= TOL and rel_err(gx.cpu().numpy(), gref.cpu().numpy()) <= TOL
     # measure='Norm' (capitalised): nfp.py:74 keeps the pure-neighbour weights while nfp.py:85 dispatches Norm
-    from neighbour_feature_pooling_amd import NFPPooling, _abi
-    from neighbour_feature_pooling_amd._host import nfp_host
-    m = NFPPooling(8, R=1, measure="Norm", p=2, padding=1)
-    x = torch.randn(2, 8, 30, 30, device=dev, requires_grad=True)
-    o = m(x)
-    assert _abi.load().nfp_last_variant().decode().startswith("fwd_tile<")
-    go = torch.randn_like(o)
-    g1, = torch.autograd.grad(o, x, go)
-    x64 = x.detach().double().requires_grad_(True)
-    r = nfp_host(x64, m.config)
-    g2, = torch.autograd.grad(r, x64, go.double())
-    assert rel_err(o.detach().cpu().numpy(), r.detach().cpu().numpy()) <= TOL
-    assert rel_err(g1.cpu().numpy(), g2.cpu().numpy()) <= TOL
+    out, gx, ref, gref, fv, bv = _run(2, 8, 30, 30, 1, "Norm", "reflect", dev)
+    assert fv.startswith("fwd_tile<") and bv.startswith("bwd_tile<")
+    assert rel_err(out.cpu().numpy(), ref.cpu().numpy()) <= TOL and rel_err(gx.cpu().numpy(), gref.cpu().numpy()) <= TOL
 
 
 @pytest.mark.parametrize("B,C,H,W,R,meas", [(3, 16, 112, 112, 1, "cosine"), (5, 24, 56, 56, 1, "norm"), (2, 128, 28, 28, 1, "cosine"),
@@ -181,9 +254,9 @@ def test_tile_kernels_dissimilarity_and_norm_quirk():
 @pytest.mark.parametrize("layout,dtype", [("nchw", torch.float32), ("nhwc", torch.float32), ("nhwc", torch.bfloat16)])
 def test_fused_pooling_tail_on_large_maps(B, C, H, W, R, meas, layout, dtype):
     """models/texture_pooling.py:249-252 averages every MultiStage map at once: GAP(x) and GAP(NFP(x)) from the row-band
-    kernels (per-band partial sums joined by pool_fold), forward and backward, against the float64 formulation."""
+    kernels (per-band partial sums joined by pool_fold), forward and backward, against the oracle (the maps' means, and
+    its backward under grad_out[b,n,:,:] = wn[b,n] / P plus wg[b,c] / P on every pixel — the adjoints of the two means)."""
     from neighbour_feature_pooling_amd import NFPPooling, _abi
-    from neighbour_feature_pooling_amd._host import nfp_host
     from neighbour_feature_pooling_amd.functional import nfp_pool, nfp_pool_fused_ok
     from neighbour_feature_pooling_amd.synth import feature_map
     dev = torch.device("cuda:0")
@@ -207,14 +280,17 @@ def test_fused_pooling_tail_on_large_maps(B, C, H, W, R, meas, layout, dtype):
     bv = L.nfp_last_variant().decode()
     assert L.nfp_launch_count() == n0 + 3, "forward band kernel + fold, one backward kernel"
     assert fv.startswith("fwd_tile<") and fv.endswith(",pool>x%s+pool_fold" % fv.split(">x")[1].split("+")[0]) and ",pool>" in bv, (fv, bv)
-    x64 = x.detach().double().contiguous().requires_grad_(True)
-    ref = nfp_host(x64, m.config)
-    rg, rn = x64.mean((2, 3)), ref.mean((2, 3))
-    (gref,) = torch.autograd.grad((rg * wg.double()).sum() + (rn * wn.double()).sum(), x64)
+    orc = _oracle()
+    xh = x.detach().float().contiguous().cpu().numpy()
+    ref = orc.forward(xh, **ctor).astype(np.float64)
+    rg, rn = xh.astype(np.float64).mean((2, 3)), ref.mean((2, 3))
+    P = H * W
+    goh = np.broadcast_to((wn.cpu().numpy() / P)[:, :, None, None], ref.shape).astype(np.float32)
+    gref = orc.backward(xh, goh, **ctor).astype(np.float64) + (wg.cpu().numpy().astype(np.float64) / P)[:, :, None, None]
     tol_o, tol_g = (1e-5, 1e-5) if dtype == torch.float32 else (1e-2, 2e-2)
-    assert rel_err(gap.detach().cpu().numpy(), rg.detach().cpu().numpy()) <= tol_o
-    assert rel_err(nfpm.detach().cpu().numpy(), rn.detach().cpu().numpy()) <= tol_o
-    assert rel_err(gx.float().cpu().numpy(), gref.cpu().numpy()) <= tol_g
+    assert rel_err(gap.detach().cpu().numpy(), rg) <= tol_o
+    assert rel_err(nfpm.detach().cpu().numpy(), rn) <= tol_o
+    assert rel_err(gx.float().cpu().numpy(), gref) <= tol_g
 
 
 def test_multistage_network_train_step_runs_on_the_large_map_kernels():

@@ -28,6 +28,35 @@ def test_oracle_matches_reference(name, oracle_lib):
         assert np.max(np.abs(a - g["gx_abs_sum"]) / g["gx_abs_sum"]) <= TOL
 
 
+def pooled_by_oracle(oracle_lib, c):
+    """adaptive_avg_pool2d(NFP(x), 1) and its input gradient from the oracle: the mean of the maps, and the backward
+    of the maps under grad_out[b,n,:,:] = g[b,n] / (Ho Wo) (the adjoint of the mean)."""
+    x = K.make_input(c)
+    out = oracle_lib.forward(x, **c["ctor"])
+    g = K.make_pool_grad(c, out.shape[1])
+    go = np.broadcast_to((g / (out.shape[2] * out.shape[3]))[:, :, None, None], out.shape).astype(np.float32)
+    return out.astype(np.float64).mean(axis=(2, 3)), oracle_lib.backward(x, go, **c["ctor"]), g
+
+
+def assert_pooled_matches_golden(nfpm, gx, g, tol, tol_gx=None):
+    tol_gx = tol if tol_gx is None else tol_gx
+    assert rel_err(nfpm, g["nfpm"]) <= tol
+    if "gx" in g:
+        assert rel_err(gx, g["gx"]) <= tol_gx
+    else:
+        assert rel_err(gx.reshape(-1)[K.gx_sample_index(gx.size)], g["gx_sample"]) <= tol_gx
+        s = gx.astype(np.float64).sum(axis=(1, 2, 3))
+        assert np.max(np.abs(s - g["gx_sum"]) / g["gx_abs_sum"]) <= tol_gx
+
+
+@pytest.mark.parametrize("name", [c["name"] for c in K.POOL_CASES])
+def test_oracle_matches_reference_pooled(name, oracle_lib):
+    """models/texture_pooling.py:251-252, 320-321: only adaptive_avg_pool2d(NFP(feat), 1) is consumed."""
+    c = K.POOL_BY_NAME[name]
+    nfpm, gx, _ = pooled_by_oracle(oracle_lib, c)
+    assert_pooled_matches_golden(nfpm, gx, load_golden(name), TOL)
+
+
 def test_oracle_strided_input_equals_contiguous(oracle_lib):
     """channels-last strides give the same answer as NCHW (the oracle reads by strides)."""
     import ctypes
