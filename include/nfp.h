@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define NFP_ABI_VERSION 5
+#define NFP_ABI_VERSION 6
 
 /* error codes */
 #define NFP_OK 0
@@ -143,6 +143,10 @@ int nfp_backward(const nfp_desc* d, const void* x, const void* grad_out, const v
  *   gap  [B,C] f32 = AdaptiveAvgPool2d(1)(x)                          NFP_Pooling.py:27
  *   nfpm [B,N] f32 = adaptive_avg_pool2d(NFPPooling(x), 1)            NFP_Pooling.py:29-31
  * out_map [B,N,Ho,Wo] (dtype of x) is also written: the backward needs it, callers may ignore it.
+ * ABI 6: `gap` may be NULL — MobileNetV3_MultiStageNFP / MidNFP consume adaptive_avg_pool2d(NFP(feat), 1) alone
+ * (texture_pooling.py:251-252, 320-321): the channel sums are then skipped; `out_map` may be NULL when no backward will
+ * follow (inference): the maps are then never stored.  nfp_pool_backward takes grad_gap = NULL likewise (GAP(x) took no
+ * part in the loss): no adjoint of the mean is added.
  * Served only where nfp_pool_supported(d) != 0 — cosine / dot / gfc / L2 / rmse on "same" maps (stride 1, padding = R),
  * NCHW or channels-last, float32 or bf16: maps of at most 512 pixels with the descriptor's workspace set, larger maps
  * with rows of W <= 254 (k = 3) / W <= 142 (k = 5) pixels — (W + 2R)(3R + 1) <= 1024, one thread per padded position of

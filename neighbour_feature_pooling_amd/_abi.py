@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libnfp_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 MEASURES = ["norm", "cosine", "dot", "rmse", "geman", "attention", "emd", "canberra", "hellinger",
             "chisquared1", "chisquared2", "gfc", "pearson", "jeffrey", "squaredchord", "smith", "scs"]

@@ -175,14 +175,22 @@ __global__ void __launch_bounds__(1024) fwd_band(const KP g, const void* __restr
 
   for (int c0 = 0; c0 < g.C; c0 += g.Cc) {
     const int ncq = min(g.Cc, g.C - c0) >> 2;
+    // Several chunks (batches beyond one workgroup per CU): the NEXT chunk's loads are issued right after this chunk's
+    // commit, so that they fly under its sums (round 3 issued them after the sums and left each workgroup with nothing in
+    // flight two thirds of the time: SQ_WAIT_ANY 42 % of the wave cycles at [4096,512,7,7], profiles/r03_p_…csv).  The
+    // staging registers stay live through the sums; with one chunk (the headline shape) nothing changes.
     if (c0 > 0) {
       __syncthreads();  // previous chunk fully consumed
-      issue(c0, ncq);
+      if (!g.pf) issue(c0, ncq);
     }
     commit(ncq);
     __syncthreads();
+    if (g.pf && c0 + g.Cc < g.C) {
+      issue(c0 + g.Cc, min(g.Cc, g.C - c0 - g.Cc) >> 2);
+      __builtin_amdgcn_sched_barrier(0);
+    }
     if (c0 == 0) NFP_STAMP(2);
-    if constexpr (POOL) {
+    if (POOL && g.pool_gap) {
       // channel sums of this chunk over the band's OWN pixels: four adjacent lanes per channel quad, lane `part` sums
       // pixels p0 + part, p0 + part + 4, ...; joined by a fixed xor tree.  One band per image: the mean goes straight to
       // gap[b][c]; several bands: the band's sum goes to its row of the scratch (pool_fold joins the bands in order).
@@ -281,7 +289,7 @@ __global__ void __launch_bounds__(1024) fwd_band(const KP g, const void* __restr
             v = g.similarity ? -dd : dd;
           }
         }
-        stx(ob, n * P + pf, v, BF ? NFP_BF16 : NFP_F32);
+        if (!POOL || g.pool_map) stx(ob, n * P + pf, v, BF ? NFP_BF16 : NFP_F32);
         if constexpr (POOL) Tt[NV + n * Ps + lpf] = v;  // vm[n][p], behind the half-stencil table
       } else if constexpr (POOL) {
         Tt[NV + n * Ps + lpf] = 0.f;                    // (an output another band writes: not part of this band's sum)

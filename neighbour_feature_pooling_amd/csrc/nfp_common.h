@@ -48,6 +48,12 @@ struct KP {
   float gf, ngf;   // (float)gfc and 1 - (float)gfc
   float uf, nuf;   // (float)unit and 1 - (float)unit: "1 if unit else v" as fmaf(v, nuf, uf) — exact, and not a branch on a
                    // wave-uniform flag in the latency-critical finalize
+  // fused pooling tail (POOL kernels): which of its by-products the caller wants.  MobileNetV3_MultiStageNFP / MidNFP
+  // consume adaptive_avg_pool2d(NFP(feat), 1) alone (texture_pooling.py:251-252, 320-321): no GAP(x) — pool_gap = 0
+  // skips the slab sums (forward) and the adjoint of the mean (backward); without a backward to follow nobody reads
+  // the maps themselves — pool_map = 0 skips their stores.
+  int pool_gap, pool_map;
+  int pf;   // fwd_band: several channel chunks — the next chunk's loads are issued under the current chunk's sums
 };
 __device__ __forceinline__ float unit_or(const KP& g, float v) { return fmaf(v, g.nuf, g.uf); }
 // GFC (nfp.py:265-276): num / (|a| |b| + eps).  Its gradient has the shape of cosine's — per pair {g', g' f}, a cross

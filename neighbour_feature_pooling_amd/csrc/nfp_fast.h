@@ -496,8 +496,8 @@ __global__ void __launch_bounds__(GEMM ? 1024 : kBwdThreads) bwd_fast(const KP g
     const int ncw = cb1 - cb0;
     const int band = Win<R>::RAD * g.W + Win<R>::RAD, KW = (32 + 2 * band + 30) >> 4;
     gg_s = (float*)(gemm_Wd + (long long)g.Tc * 2 * 32 * odd_up(2 * KW + 1));
-    if (t < ncw) ggv0 = ggap[(long long)b * g.C + cb0 + t];
-    if (t + T < ncw) ggv1 = ggap[(long long)b * g.C + cb0 + t + T];
+    if (g.pool_gap && t < ncw) ggv0 = ggap[(long long)b * g.C + cb0 + t];
+    if (g.pool_gap && t + T < ncw) ggv1 = ggap[(long long)b * g.C + cb0 + t + T];
   }
   const int gl = fast_div(t, g.invP), p = t - gl * P;
   const bool active = gl < g.G;
@@ -658,7 +658,7 @@ __global__ void __launch_bounds__(GEMM ? 1024 : kBwdThreads) bwd_fast(const KP g
     const int ncw = cb1 - cb0;
     if (t < ncw) gg_s[t] = ggv0 * g.invP;
     if (t + T < ncw) gg_s[t + T] = ggv1 * g.invP;
-    for (int i = t + 2 * T; i < ncw; i += T) gg_s[i] = ggap[(long long)b * g.C + cb0 + i] * g.invP;  // (more than 2T channels)
+    for (int i = t + 2 * T; i < ncw; i += T) gg_s[i] = g.pool_gap ? ggap[(long long)b * g.C + cb0 + i] * g.invP : 0.f;  // (more than 2T channels)
   }
   __syncthreads();
   NFP_STAMP(2);
@@ -847,7 +847,7 @@ __global__ void __launch_bounds__(GEMM ? 1024 : kBwdThreads) bwd_fast(const KP g
       for (int cq = gl; cq < ncq; cq += g.G) {
         const float4* row = slab + cq * Pp + sp;
         float4 r4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if constexpr (POOL) {
+        if (POOL && g.pool_gap) {
           const float4 gg = *(const float4*)(ggap + (long long)b * g.C + c0 + 4 * cq);
           r4 = make_float4(gg.x * g.invP, gg.y * g.invP, gg.z * g.invP, gg.w * g.invP);
         }

@@ -82,6 +82,7 @@ int make_kp(const nfp_desc* d, KP* g) {
   g->nuf = 1.0f - g->uf;
   g->osa = prod ? (g->similarity ? 1.f : -1.f) : (g->similarity ? -1.f : 1.f);
   g->osb = (d->measure == NFP_COSINE && !g->similarity) ? 1.f : 0.f;
+  g->pool_gap = g->pool_map = 1;
   g->d2s = d->measure == NFP_RMSE ? 1.0f / (float)d->C : 1.0f;
   g->zero0 = d->measure == NFP_RMSE ? 0 : 1;
   // index arithmetic of the general kernels: coordinates in 15 bits, pair indices in 31
@@ -423,6 +424,12 @@ int launch_fwd_band_t(KP g, const void* x, void* out, float* saved, hipStream_t 
   if (ncq < 1) return kNotApplicable;
   const int total = g.C / 4, nch = (total + ncq - 1) / ncq;
   g.Cc = 4 * ((total + nch - 1) / nch);
+#ifndef NFP_BAND_PF
+#define NFP_BAND_PF 1
+#endif
+  // (measured, profiles/r04_a_…: [4096,512,7,7] forward 84.8 -> 83.1 us cold, 81.6 -> 80.0 resident; k = 5 loses 1-3 %:
+  // its sums already hide the next chunk's latency behind four times the LDS reads)
+  g.pf = (NFP_BAND_PF && nch > 1 && Win<R>::RAD == 1) ? 1 : 0;
   const size_t slab = (size_t)(g.Cc / 4) * ppb * 16;
   const size_t tail = (size_t)psm * (NF + 1) * 4 + (POOL ? (size_t)Win<R>::N * psm * 4 : 0);   // Tt (+ pooled-map staging)
   const size_t lds = slab + tail;
@@ -521,9 +528,9 @@ int launch_fwd_gram(const KP& g, const void* x, void* out, float* saved, hipStre
   if (g.contig && tiles + image > (size_t)kLdsMax) return kNotApplicable;  // NCHW is transposed through LDS only
   if (tiles + (size_t)g.P * 8 > (size_t)kLdsMax) return kNotApplicable;  // (the norm tables reuse the image's words)
   // the pooled variant takes its sums from the LDS image and stages the map values in it afterwards
-  if (gap != nullptr && (tiles + image > (size_t)kLdsMax || image < (size_t)(2 + Win<R>::N) * g.P * 4)) return kNotApplicable;
+  if (nfpm != nullptr && (tiles + image > (size_t)kLdsMax || image < (size_t)(2 + Win<R>::N) * g.P * 4)) return kNotApplicable;
   snprintf(g_variant, sizeof(g_variant), "fwd_gram<R%d,%s,bf16,%s%s>", R, hot_name(g),
-           g.contig ? "nchw" : "nhwc", gap != nullptr ? ",pool" : "");
+           g.contig ? "nchw" : "nhwc", nfpm != nullptr ? ",pool" : "");
   if (g.contig)
     return launch("fwd_gram", fwd_gram<R, M, true, true>, dim3(g.B), dim3(1024), tiles + image, st, g, x, out, saved, D, g.ws,
                   gap, nfpm);
@@ -1026,9 +1033,11 @@ int nfp_pool_forward(const nfp_desc* d, const void* x, float* gap, float* nfpm, 
                      void* hip_stream) {
   KP g;
   if (int rc = make_kp(d, &g)) return rc;
-  if (!x || !gap || !nfpm || !out_map) return fail(NFP_E_INVALID, "null tensor pointer");
+  if (!x || !nfpm) return fail(NFP_E_INVALID, "null tensor pointer");
   if (!pool_measure_ok(g)) return fail(NFP_E_UNSUPPORTED, "fused pooling tail: cosine / dot / gfc / L2 (norm p=2) / rmse, one radius");
   if (g.B == 0) return NFP_OK;
+  g.pool_gap = gap != nullptr ? 1 : 0;       // NULL: GAP(x) is not wanted (texture_pooling.py:251-252)
+  g.pool_map = out_map != nullptr ? 1 : 0;   // NULL: no backward will follow, nobody reads the maps
   hipStream_t st = (hipStream_t)hip_stream;
   int rc;
   if (hot_product(g))
@@ -1044,10 +1053,11 @@ int nfp_pool_backward(const nfp_desc* d, const void* x, const float* grad_gap, c
                       const void* out_map, const float* saved, void* grad_x, void* hip_stream) {
   KP g;
   if (int rc = make_kp(d, &g)) return rc;
-  if (!x || !grad_gap || !grad_nfpm || !out_map || !grad_x) return fail(NFP_E_INVALID, "null tensor pointer");
+  if (!x || !grad_nfpm || !out_map || !grad_x) return fail(NFP_E_INVALID, "null tensor pointer");
   if (!pool_measure_ok(g)) return fail(NFP_E_UNSUPPORTED, "fused pooling tail: cosine / dot / gfc / L2 (norm p=2) / rmse, one radius");
   if (stats_of(g.measure) > 0 && !saved) return fail(NFP_E_INVALID, "missing saved state");
   if (g.B == 0) return NFP_OK;
+  g.pool_gap = grad_gap != nullptr ? 1 : 0;  // NULL: GAP(x) took no part in the loss (or was never produced)
   hipStream_t st = (hipStream_t)hip_stream;
   int rc;
   if (hot_product(g))

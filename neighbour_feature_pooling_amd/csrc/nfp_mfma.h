@@ -166,7 +166,7 @@ __global__ void __launch_bounds__(1024) fwd_gram(const KP g, const void* __restr
       const float dd = __builtin_amdgcn_sqrtf(d2);
       v = g.similarity ? -dd : dd;
     }
-    stx(ob, n * P + p, v, NFP_BF16);
+    if (nfpm == nullptr || g.pool_map) stx(ob, n * P + p, v, NFP_BF16);
     if (nfpm != nullptr) vm[n * P + p] = v;
   }
   if (M == NFP_COSINE && saved != nullptr && gl == 0) saved[(long long)b * P + p] = __builtin_amdgcn_sqrtf(n2p);

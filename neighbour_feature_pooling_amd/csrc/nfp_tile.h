@@ -321,7 +321,7 @@ __global__ void __launch_bounds__(1024, (R == 1 ? 8 : 4)) fwd_tile(const KP g, c
     // the next chunk's loads fly while this one is summed (the staging registers are free once committed)
     if (c0 + g.Cc < g.C) st.issue(g, ps, xb, G, c0 + g.Cc, min(g.Cc, g.C - c0 - g.Cc) >> 2, npu);
     if (c0 == 0) NFP_STAMP(2);
-    if constexpr (POOL) {
+    if (POOL && g.pool_gap) {
       // this band's share of sum over pixels of x[c]: (channel quad, segment of the band's pixels) items dealt over the
       // FULL wavefronts (the DPP tree reads all 64 lanes; a workgroup's last wavefront may be partial); lanes stride over
       // the segment's pixels; one writer per (segment, channel).  pool_fold joins segments and bands in a fixed order.
@@ -416,7 +416,8 @@ __global__ void __launch_bounds__(1024, (R == 1 ? 8 : 4)) fwd_tile(const KP g, c
   if (ps.own) {
     const int p = ps.y * W + ps.x;
     // (buffer stores: one offset register for all N maps of the pixel, the map through the scalar offset)
-    const Rsrc ob = make_rsrc((char*)out + (long long)b * N * P * ES, (long long)N * P * ES);
+    // (POOL without a backward to follow: nobody reads the maps — an empty resource drops the stores in the memory pipeline)
+    const Rsrc ob = make_rsrc((char*)out + (long long)b * N * P * ES, (!POOL || g.pool_map) ? (long long)N * P * ES : 0);
     auto one = [&](int n, auto statc) {
       constexpr bool stat = decltype(statc)::value;
       int dy, dx;
@@ -485,8 +486,10 @@ __global__ void __launch_bounds__(256) pool_fold(const float* __restrict__ part,
                                                  float* __restrict__ nfpm, int B, int nb, int C, int N, float invP) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const int CN = C + N;
-  if (i >= (long long)B * CN) return;
-  const int b = (int)(i / CN), k = (int)(i - (long long)b * CN);
+  // (gap == nullptr: the bands wrote no channel sums — only the N map sums of every image are folded)
+  const int per = gap != nullptr ? CN : N, k0 = gap != nullptr ? 0 : C;
+  if (i >= (long long)B * per) return;
+  const int b = (int)(i / per), k = k0 + (int)(i - (long long)b * per);
   // (the rows in a fixed order; eight loads in flight at a time — one dependent load per row is a latency chain: 19 rows
   // took 13 us of a 35 us pooled tail)
   const float* pr = part + (long long)b * nb * CN + k;
@@ -709,7 +712,10 @@ __global__ void __launch_bounds__(1024, (R == 1 ? (CST ? 5 : 8) : 4)) bwd_tile(c
 #pragma unroll
       for (int j = 0; j < K2; ++j) {
         // (u's own centre is not a position of r's window: the copy's pull on itself is the pixel's own — below)
-        const bool ok = oky[j / K] && okx[j % K] && !(j / K + sy == R && j % K + sx == R);
+        // (Norm p = 1 on the difference weights: u's slot that points at r ITSELF — a pixel and its own padded copy,
+        // replicate padding; reflect with R = 2 — lands on r's centre slot, which multiplies sign(x_r) here, not x_r: the
+        // pair's gradient is sign(x_u - x_r) = sign(0) = 0, so it is dropped.  The linear measures add it: it multiplies x_r.)
+        const bool ok = oky[j / K] && okx[j % K] && !(j / K + sy == R && j % K + sx == R) && !(M == kNormP1 && j == K2 / 2);
         const float val = wu[j];
         w[j] += ok ? val : 0.f;
       }
@@ -737,7 +743,7 @@ __global__ void __launch_bounds__(1024, (R == 1 ? (CST ? 5 : 8) : 4)) bwd_tile(c
     auto one = [&](int cq) {
       const float4* rc = slab + cq * Ppb + v - R;
       float4 r4 = make_float4(0.f, 0.f, 0.f, 0.f);
-      if constexpr (POOL) {
+      if (POOL && g.pool_gap) {
         const float4 gg = *(const float4*)(ggap + (long long)b * g.C + c0 + 4 * cq);
         r4 = make_float4(gg.x * g.invP, gg.y * g.invP, gg.z * g.invP, gg.w * g.invP);
       }

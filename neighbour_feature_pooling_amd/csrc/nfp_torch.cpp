@@ -64,19 +64,23 @@ struct NfpNode : torch::autograd::Function<NfpNode> {
   }
 };
 
+// want_gap: GAP(x) is part of the result (NFP_Pooling.py:27); false: the pooled NFP maps alone (texture_pooling.py:251-252)
+// — an empty tensor stands in for it.  need_grad: a backward will follow — only then are the maps themselves stored.
 struct NfpPoolNode : torch::autograd::Function<NfpPoolNode> {
   static variable_list forward(AutogradContext* ctx, Tensor x, Tensor desc, std::vector<int64_t> oshape, int64_t ns,
-                               bool nhwc) {
+                               bool nhwc, bool want_gap, bool need_grad) {
     c10::DeviceGuard guard(x.device());
     const nfp_desc* d = desc_of(desc);
     const auto f32 = x.options().dtype(torch::kFloat32).memory_format(at::MemoryFormat::Contiguous);
-    Tensor gap = torch::empty({oshape[0], x.size(1)}, f32), nfpm = torch::empty({oshape[0], oshape[1]}, f32);
-    Tensor omap = torch::empty(oshape, x.options().memory_format(at::MemoryFormat::Contiguous));
+    Tensor gap = torch::empty({want_gap ? oshape[0] : 0, x.size(1)}, f32), nfpm = torch::empty({oshape[0], oshape[1]}, f32);
+    Tensor omap = need_grad ? torch::empty(oshape, x.options().memory_format(at::MemoryFormat::Contiguous))
+                            : torch::empty({0}, x.options());
     Tensor saved = torch::empty({ns}, f32);
-    check(nfp_pool_forward(d, x.data_ptr(), gap.data_ptr<float>(), nfpm.data_ptr<float>(), omap.data_ptr(),
-                           ns > 0 ? saved.data_ptr<float>() : nullptr, stream_of(x)));
+    check(nfp_pool_forward(d, x.data_ptr(), want_gap ? gap.data_ptr<float>() : nullptr, nfpm.data_ptr<float>(),
+                           need_grad ? omap.data_ptr() : nullptr, ns > 0 ? saved.data_ptr<float>() : nullptr, stream_of(x)));
     ctx->save_for_backward({x, omap, saved, desc});
     ctx->saved_data["nhwc"] = nhwc;
+    ctx->saved_data["want_gap"] = want_gap;
     return {gap, nfpm};
   }
   static variable_list backward(AutogradContext* ctx, variable_list grads) {
@@ -85,21 +89,24 @@ struct NfpPoolNode : torch::autograd::Function<NfpPoolNode> {
     c10::DeviceGuard guard(x.device());
     const auto f32 = x.options().dtype(torch::kFloat32);
     // a pooled output that took no part in the loss arrives undefined: its gradient is zero
-    Tensor ggap = grads[0].defined() ? grads[0].contiguous().to(torch::kFloat32) : torch::zeros({x.size(0), x.size(1)}, f32);
+    // (grad_gap = NULL: GAP(x) was not produced, or took no part in the loss — no adjoint of the mean, include/nfp.h)
+    const bool has_gap = ctx->saved_data["want_gap"].toBool() && grads[0].defined();
+    Tensor ggap = has_gap ? grads[0].contiguous().to(torch::kFloat32) : Tensor();
     Tensor gnfp = grads[1].defined() ? grads[1].contiguous().to(torch::kFloat32)
                                      : torch::zeros({omap.size(0), omap.size(1)}, f32);
     Tensor gx = empty_like_layout(x, ctx->saved_data["nhwc"].toBool());
-    check(nfp_pool_backward(desc_of(desc), x.data_ptr(), ggap.data_ptr<float>(), gnfp.data_ptr<float>(), omap.data_ptr(),
-                            saved.numel() ? saved.data_ptr<float>() : nullptr, gx.data_ptr(), stream_of(x)));
-    return {gx, Tensor(), Tensor(), Tensor(), Tensor()};
+    check(nfp_pool_backward(desc_of(desc), x.data_ptr(), has_gap ? ggap.data_ptr<float>() : nullptr, gnfp.data_ptr<float>(),
+                            omap.data_ptr(), saved.numel() ? saved.data_ptr<float>() : nullptr, gx.data_ptr(), stream_of(x)));
+    return {gx, Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
   }
 };
 
 Tensor nfp_apply(Tensor x, Tensor desc, std::vector<int64_t> oshape, int64_t ns, bool nhwc) {
   return NfpNode::apply(x, desc, oshape, ns, nhwc);
 }
-std::vector<Tensor> nfp_pool_apply(Tensor x, Tensor desc, std::vector<int64_t> oshape, int64_t ns, bool nhwc) {
-  return NfpPoolNode::apply(x, desc, oshape, ns, nhwc);
+std::vector<Tensor> nfp_pool_apply(Tensor x, Tensor desc, std::vector<int64_t> oshape, int64_t ns, bool nhwc, bool want_gap,
+                                   bool need_grad) {
+  return NfpPoolNode::apply(x, desc, oshape, ns, nhwc, want_gap, need_grad);
 }
 
 }  // namespace

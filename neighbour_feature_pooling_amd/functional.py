@@ -319,24 +319,28 @@ class _NfpHip(torch.autograd.Function):
 
 
 class _NfpPoolHip(torch.autograd.Function):
-    """(gap [B,C], nfpm [B,N]) = fused tail of models/NFP_Pooling.py:27-31 in one pass over x."""
+    """(gap [B,C], nfpm [B,N]) = fused tail of models/NFP_Pooling.py:27-31 in one pass over x.  want_gap = False: the
+    pooled NFP maps alone (texture_pooling.py:251-252, 320-321) — gap comes back empty and its sums are never taken;
+    need_grad = False: the maps themselves are not stored either (include/nfp.h, ABI 6)."""
 
     @staticmethod
-    def forward(ctx, x, cfg):
+    def forward(ctx, x, cfg, want_gap, need_grad):
         L = _abi.load()
         x, layout = _dense(x)
         d, (B, N, Ho, Wo), _, _ = _plan(x, layout, cfg)
         ns = _pool_saved_floats(x, layout, cfg, d)
         with _on_device(x.device):
-            gap = torch.empty(B, x.shape[1], dtype=torch.float32, device=x.device)
+            gap = torch.empty(B if want_gap else 0, x.shape[1], dtype=torch.float32, device=x.device)
             nfpm = torch.empty(B, N, dtype=torch.float32, device=x.device)
-            out_map = torch.empty(B, N, Ho, Wo, dtype=x.dtype, device=x.device)
+            out_map = torch.empty((B, N, Ho, Wo) if need_grad else (0,), dtype=x.dtype, device=x.device)
             saved = torch.empty(max(ns, 0), dtype=torch.float32, device=x.device)
             stream = _raw_stream(x.device)
-            _abi.check(L.nfp_pool_forward(ctypes.byref(d), x.data_ptr(), gap.data_ptr(), nfpm.data_ptr(),
-                                          out_map.data_ptr(), saved.data_ptr() if ns > 0 else None, stream))
+            _abi.check(L.nfp_pool_forward(ctypes.byref(d), x.data_ptr(), gap.data_ptr() if want_gap else None,
+                                          nfpm.data_ptr(), out_map.data_ptr() if need_grad else None,
+                                          saved.data_ptr() if ns > 0 else None, stream))
         ctx.desc = d
         ctx.layout = layout
+        ctx.want_gap = want_gap
         ctx.save_for_backward(x, out_map, saved)
         return gap, nfpm
 
@@ -345,16 +349,17 @@ class _NfpPoolHip(torch.autograd.Function):
     def backward(ctx, g_gap, g_nfpm):
         x, out_map, saved = ctx.saved_tensors
         L = _abi.load()
-        g_gap = g_gap.contiguous().float()
+        g_gap = g_gap.contiguous().float() if ctx.want_gap else None
         g_nfpm = g_nfpm.contiguous().float()
         with _on_device(x.device):
             gx = torch.empty(x.shape, dtype=x.dtype, device=x.device,
                              memory_format=torch.channels_last if ctx.layout == "nhwc" else torch.contiguous_format)
             stream = _raw_stream(x.device)
-            _abi.check(L.nfp_pool_backward(ctypes.byref(ctx.desc), x.data_ptr(), g_gap.data_ptr(), g_nfpm.data_ptr(),
+            _abi.check(L.nfp_pool_backward(ctypes.byref(ctx.desc), x.data_ptr(),
+                                           g_gap.data_ptr() if g_gap is not None else None, g_nfpm.data_ptr(),
                                            out_map.data_ptr(), saved.data_ptr() if saved.numel() else None,
                                            gx.data_ptr(), stream))
-        return gx, None
+        return gx, None, None, None
 
 
 def _pool_saved_floats(x, layout, cfg, d):
@@ -406,15 +411,23 @@ def _amp_input(x):
     return x, None
 
 
-def nfp_pool(x, cfg):
+def nfp_pool(x, cfg, want_gap=True):
     """(GAP(x) [B,C], GAP(NFP(x)) [B,N]) — NFP_Pooling.py:27-31.  Fused on the GPU where supported,
-    otherwise the same two reductions composed from `nfp` and torch ops."""
+    otherwise the same two reductions composed from `nfp` and torch ops.  want_gap = False: (None, GAP(NFP(x))) — the
+    channel sums of x are not taken (nfp_pooled)."""
     xin, cast = _amp_input(x)
     if xin is not x:
         with torch.autocast("cuda", enabled=False):
-            gap, nfpm = nfp_pool(xin, cfg)
-        return (gap, nfpm) if cast is None else (gap.to(cast), nfpm.to(cast))
+            gap, nfpm = nfp_pool(xin, cfg, want_gap)
+        return (gap, nfpm) if cast is None else (None if gap is None else gap.to(cast), nfpm.to(cast))
+    if x.is_cuda and torch.compiler.is_compiling() and x.dim() == 4:
+        # under torch.compile: the registered custom op (one node in the compiled graph, no graph break) — _ops.py
+        from . import _ops
+        need_grad = x.requires_grad and torch.is_grad_enabled()
+        gap, nfpm, _, _ = torch.ops.nfp_amd.nfp_pool(x, *_ops.cfg_args(cfg), bool(want_gap), bool(need_grad))
+        return (gap if want_gap else None), nfpm
     if x.dim() == 4 and nfp_pool_fused_ok(x, cfg):
+        need_grad = x.requires_grad and torch.is_grad_enabled()
         try:
             cpp = _cpp_nodes()
             if cpp:
@@ -422,12 +435,20 @@ def nfp_pool(x, cfg):
                 d, oshape, _, _ = _plan(xd, layout, cfg)
                 ns = _pool_saved_floats(xd, layout, cfg, d)
                 gap, nfpm = _cpp_call(cpp.nfp_pool_apply, xd, _DESC_TENSORS[id(d)][1], list(oshape), max(ns, 0),
-                                      layout == "nhwc")
-                return gap, nfpm
-            return _NfpPoolHip.apply(x, cfg)
+                                      layout == "nhwc", bool(want_gap), bool(need_grad))
+            else:
+                gap, nfpm = _NfpPoolHip.apply(x, cfg, bool(want_gap), bool(need_grad))
+            return (gap if want_gap else None), nfpm
         except _abi.NfpUnsupported:
             pass    # (nfp_pool_supported is a dry run of both launchers; should it ever disagree, the composition serves)
-    return x.mean((2, 3)), nfp(x, cfg).mean((2, 3))
+    return (x.mean((2, 3)) if want_gap else None), nfp(x, cfg).mean((2, 3))
+
+
+def nfp_pooled(x, cfg):
+    """adaptive_avg_pool2d(NFPPooling(x), 1).flatten(1) — [B, N] float32 — as MobileNetV3_MultiStageNFP and MidNFP consume
+    their NFP layers (models/texture_pooling.py:251-252, 320-321): no GAP(x) beside it.  On the GPU one pass over x that
+    neither sums the channels of x nor, without a gradient to follow, stores the maps."""
+    return nfp_pool(x, cfg, want_gap=False)[1]
 
 
 def nfp_multi_radius(x, cfg1, cfg2):
@@ -456,6 +477,11 @@ def nfp(x, cfg):
         with torch.autocast("cuda", enabled=False):
             out = nfp(xin, cfg)
         return out if cast is None else out.to(cast)
+    if x.is_cuda and torch.compiler.is_compiling() and cfg.measure != "scs":
+        # under torch.compile: the registered custom op (one node in the compiled graph, no graph break) — _ops.py
+        from . import _ops
+        need_grad = x.requires_grad and torch.is_grad_enabled()
+        return torch.ops.nfp_amd.nfp(x, *_ops.cfg_args(cfg), bool(need_grad))[0]
     if x.is_cuda and cfg.measure == "scs":
         # The one measure without a kernel, on purpose: the reference's SharpenedCosine divides
         # (B,N,H,W) by (B,1,N,H,W) and so averages over the BATCH (nfp.py:359-374).  Its exact behaviour

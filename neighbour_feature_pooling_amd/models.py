@@ -223,8 +223,9 @@ class MultiStageNFPNet(nn.Module):
         self.fc = nn.Linear(head_width, num_classes)
 
     def forward(self, x):
-        from .functional import nfp_pool
+        from .functional import nfp_pooled
         feats = self.backbone.forward_stages(x)
-        v = torch.cat([nfp_pool(f, layer.config)[1].to(f.dtype) for f, layer in zip(feats, self.nfps)], dim=1)   # [B, 40]
+        # texture_pooling.py:251-252: F.adaptive_avg_pool2d(nfp(feat), 1) per stage — the pooled maps alone, no GAP(feat)
+        v = torch.cat([nfp_pooled(f, layer.config).to(f.dtype) for f, layer in zip(feats, self.nfps)], dim=1)   # [B, 40]
         head = self.conv_head(feats[-1]).mean((2, 3))
         return self.fc(head * self.nfp_proj(v))

@@ -56,7 +56,8 @@ class NFPPooling(nn.Module):
         if cached is not None and cached[0] == sig:
             return cached[1]
         cfg = self._build_config()
-        self.__dict__["_cfg_cache"] = (sig, cfg)
+        if not torch.compiler.is_compiling():      # (no attribute mutation inside a traced forward)
+            self.__dict__["_cfg_cache"] = (sig, cfg)
         return cfg
 
     def _build_config(self):

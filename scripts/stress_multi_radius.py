@@ -17,12 +17,14 @@ def one_case(rnd, dev):
     B = rnd.choice([1, 2, 5, 33, 70, 300, 1100])
     if B * C * H * W > 6_000_000:
         B = 5
-    meas = rnd.choice(["cosine", "cosine", "norm", "dot", "gfc", "rmse"])
+    meas = rnd.choice(["cosine", "cosine", "norm", "dot", "gfc", "rmse", "norm1", "emd"])
     mode = rnd.choice(["reflect", "zeros", "replicate"])
     cl, bf = rnd.random() < 0.5, rnd.random() < 0.25
     kw = dict(padding_mode=mode)
     if meas == "norm":
         kw["p"] = 2
+    if meas == "norm1":     # the class default (nfp.py:16)
+        meas, kw["p"] = "norm", 1
     m = MultiRadiusNFPPooling(C, R_list=(1, 2), measure=meas, **kw)
     dt = torch.bfloat16 if bf else torch.float32
     x = torch.from_numpy(feature_map((B, C, H, W), rnd.randint(0, 1 << 20))).to(dev).to(dt)

@@ -10,7 +10,7 @@ from bench import time_kernel_graph, algorithmic_bytes
 L = _abi.load()
 s = torch.cuda.Stream()
 out_f = open(sys.argv[1], "w") if len(sys.argv) > 1 else None
-shapes = [(64, 512, 7, 1), (256, 192, 14, 2)]
+shapes = [(64, 512, 7, 1), (256, 192, 14, 2), (256, 64, 56, 1)]   # headline, config 5 (f32), a RESNET18_NFP_AT_LAYER map
 for B, C, S, R in shapes:
     for meas in _abi.MEASURES:
         if meas == "scs":
@@ -22,12 +22,15 @@ for B, C, S, R in shapes:
             with torch.cuda.stream(s):
                 o = m(x)
                 fv = L.nfp_last_variant().decode()
+                torch.autograd.grad(o, x, go, retain_graph=True)
+                torch.cuda.synchronize()
+                bv = L.nfp_last_variant().decode()
                 tf = time_kernel_graph(lambda: m(x), 20, s)
                 tb = time_kernel_graph(lambda: torch.autograd.grad(o, x, go, retain_graph=True), 20, s)
             fb, bb = algorithmic_bytes(B, C, S * S, m.out_channels, 4)
             row = dict(shape=[B, C, S, S], k=2 * R + 1, measure=meas, p=p, fwd_us=round(tf, 2), bwd_us=round(tb, 2),
                        fwd_GBs=round(fb / tf / 1e3), bwd_GBs=round(bb / tb / 1e3),
-                       Mpx_s=round(B * S * S / (tf + tb), 1), variant=fv)
+                       Mpx_s=round(B * S * S / (tf + tb), 1), variant=fv, bwd_variant=bv)
             print(json.dumps(row), flush=True)
             if out_f:
                 out_f.write(json.dumps(row) + "\n"); out_f.flush()

@@ -290,13 +290,14 @@ def test_no_grad_and_requires_grad_false(dev):
 # ---- end-to-end configs (BASELINE.json configs 3 and 5 geometry) -------------------
 
 def test_resnet18_nfp_train_step_eurosat_shape(dev):
-    """Config 3: ResNet18+NFP(cosine) on 13-channel 64x64 input; NFP sees [B,512,2,2]."""
+    """Config 3 (BASELINE.json configs[2]) at its configured batch: ResNet18+NFP(cosine) on [256,13,64,64]; NFP sees
+    [256,512,2,2] (reflect padding on a 2x2 map)."""
     from neighbour_feature_pooling_amd import _abi
     from neighbour_feature_pooling_amd.train import build, make_step, synthetic_batch
     torch.manual_seed(0)
     net = build("resnet18", num_classes=10, in_chans=13, image=64, device=dev)
     step, _ = make_step(net)
-    x, y = synthetic_batch(32, 13, 64, 10, dev, torch.float32, 3)
+    x, y = synthetic_batch(256, 13, 64, 10, dev, torch.float32, 3)
     n0 = _abi.load().nfp_launch_count()
     l0 = step(x, y)
     for _ in range(4):
@@ -1074,12 +1075,17 @@ def test_multi_radius_falls_back_to_two_passes(dev):
     from neighbour_feature_pooling_amd import MultiRadiusNFPPooling, _abi
     x = torch.randn(2, 16, 9, 9, device=dev)
     for kw, fused in ((dict(R_list=(1, 2), measure="cosine", padding_mode="replicate"), None),
-                      (dict(R_list=(1, 2), measure="dot"), False), (dict(R_list=(2, 3), measure="cosine"), False)):
+                      (dict(R_list=(1, 2), measure="dot"), True),           # round 4: every hot measure is fused, p = 1 / EMD too
+                      (dict(R_list=(1, 2), measure="norm", p=1), True), (dict(R_list=(1, 2), measure="emd"), True),
+                      (dict(R_list=(1, 2), measure="canberra"), False), (dict(R_list=(1, 2), measure="norm", p=3), False),
+                      (dict(R_list=(2, 3), measure="cosine"), False)):
         m = MultiRadiusNFPPooling(16, **kw)
         n0 = _launches()
         y = m(x)
         n = _launches() - n0
         assert n >= (2 if fused is False else 1)
+        if fused is True:
+            assert n == 1 and _abi.load().nfp_last_variant().decode().startswith("fwd_band<R1+2,"), kw
         ref = torch.cat([b(x) for b in m.nfp_blocks], dim=1)
         assert (y - ref).abs().max().item() <= 2e-6
 
@@ -1336,6 +1342,35 @@ def test_workspace_fill_is_ordered_before_a_plan_cache_hit_on_another_stream(dev
     torch.cuda.synchronize()
     assert functional._PENDING_FILLS == []
     assert torch.equal(ya, yc) and torch.equal(yb, yc)
+
+
+@pytest.mark.parametrize("pooled", [False, True])
+def test_torch_compile_fullgraph_runs_the_hip_kernels(pooled, dev):
+    """A model holding NFPPooling / nfp_pooling compiles as ONE graph (fullgraph=True raises on any break) — the registered
+    custom ops of _ops.py stand for the op inside it — and the compiled forward / backward launch the same HIP kernels
+    and give the eager results; torch.library.opcheck validates schema, fake implementation and autograd registration."""
+    from test_compile import Net
+    from neighbour_feature_pooling_amd import _abi, _ops
+    from neighbour_feature_pooling_amd.functional import NfpConfig
+    torch.manual_seed(0)
+    net = Net(pooled, device="cuda")
+    x = torch.randn(4, 3, 9, 9, device=dev)
+    ref = net(x)
+    ref.square().sum().backward()
+    g_ref = net.conv.weight.grad.clone()
+    net.zero_grad()
+    n0 = _launches()
+    y = torch.compile(net, fullgraph=True, backend="aot_eager")(x)
+    y.square().sum().backward()
+    torch.cuda.synchronize()
+    assert _launches() >= n0 + 2
+    assert torch.allclose(y, ref, atol=1e-6) and torch.allclose(net.conv.weight.grad, g_ref, atol=1e-5)
+    cfg = NfpConfig(R=1, measure="cosine", padding=1)
+    xs = torch.randn(2, 16, 9, 9, device=dev, requires_grad=True)
+    torch.library.opcheck(torch.ops.nfp_amd.nfp.default, (xs, *_ops.cfg_args(cfg), True),
+                          test_utils=("test_schema", "test_faketensor", "test_autograd_registration"))
+    torch.library.opcheck(torch.ops.nfp_amd.nfp_pool.default, (xs, *_ops.cfg_args(cfg), True, True),
+                          test_utils=("test_schema", "test_faketensor", "test_autograd_registration"))
 
 
 def _load_script(name):

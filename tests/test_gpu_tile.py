@@ -113,7 +113,10 @@ def test_tile_kernels_one_thread_per_position_on_a_full_chip(B, C, H, W, R, meas
 
 ROW_BAND_GOLDENS = ["ms_cos_112x112x16", "ms_cos_56x56x24", "ms_cos_28x28x40", "rn_cos_56x56x64", "rn_cos_28x28x128",
                     "tile_l2_k5_112x112x16", "tile_cos_k5_40x40x24", "tile_cos_zeros_56x56x24", "tile_cos_replicate_56x56x24",
-                    "tile_l2_replicate_k5_30x37x8", "tile_rmse_40x40x16", "tile_gfc_40x40x16", "tile_dot_40x40x16"]
+                    "tile_l2_replicate_k5_30x37x8", "tile_rmse_40x40x16", "tile_gfc_40x40x16", "tile_dot_40x40x16",
+                    # the class default Norm p = 1 (nfp.py:16), its 'Norm' quirk, and EMD = the same sum (nfp.py:207-216)
+                    "tile_norm_p1_40x40x16", "tile_norm_p1_k5_zeros_30x37x8", "tile_emd_dissim_40x40x16",
+                    "tile_norm_p1_quirk_40x40x8"]
 
 
 @pytest.mark.parametrize("name", ROW_BAND_GOLDENS)
@@ -142,6 +145,24 @@ def test_row_band_kernels_match_reference_golden(name, channels_last):
     assert_matches_golden(out.detach().cpu().numpy(), gx.cpu().numpy(), load_golden(name), TOL, 2 * TOL)
 
 
+@pytest.mark.parametrize("B,C,H,W,R,meas,mode", [
+    (3, 16, 112, 112, 1, "norm", "reflect"), (2, 64, 56, 56, 1, "norm", "reflect"), (2, 24, 56, 56, 2, "norm", "replicate"),
+    (9, 8, 30, 37, 1, "emd", "zeros"), (2, 12, 23, 46, 2, "emd", "reflect"), (200, 16, 40, 40, 1, "norm", "reflect"),
+    (1, 260, 26, 26, 1, "Norm", "reflect"), (2, 16, 6, 100, 2, "Norm", "zeros"),
+    (3, 8, 33, 31, 1, "norm", "replicate"), (2, 8, 30, 37, 2, "Norm", "replicate")])   # a pixel and its own padded copy
+@pytest.mark.parametrize("layout,dtype", [("nchw", torch.float32), ("nhwc", torch.float32), ("nhwc", torch.bfloat16)])
+def test_class_default_norm_p1_and_emd_on_the_row_band_kernels(B, C, H, W, R, meas, mode, layout, dtype):
+    """NFPPooling() defaults to measure='norm', p=1 (nfp.py:16,141-148); EMD (nfp.py:207-216) is the same sum.  Round 3
+    served them above 512 pixels with the any-geometry kernels (0.13-0.25 of the roofline); now fwd_tile / bwd_tile<...,l1>:
+    sums of |a - b|, a gradient in sign(a - b).  Against the oracle, 'Norm' quirk (pure-neighbour weights) included."""
+    dev = torch.device("cuda:0")
+    out, gx, ref, gref, fv, bv = _run(B, C, H, W, R, meas, mode, dev, dtype=dtype, channels_last=layout == "nhwc", p=1)
+    assert fv.startswith("fwd_tile<R%d,l1," % R) and bv.startswith("bwd_tile<R%d,l1," % R), (fv, bv)
+    to, tg = (TOL, TOL) if dtype == torch.float32 else (1e-2, 2e-2)
+    assert rel_err(out.float().cpu().numpy(), ref.numpy()) <= to, fv
+    assert rel_err(gx.float().cpu().numpy(), gref.numpy()) <= tg, bv
+
+
 def test_row_band_kernels_with_poisoned_lds():
     """the row-band kernels let taps past the padded band read "whatever lies there" on the argument
     that nobody looks such a value up.  The -DNFP_LDS_POISON build (libnfp_hip_poison.so, build.py) fills every word of a
@@ -152,7 +173,7 @@ def test_row_band_kernels_with_poisoned_lds():
         pytest.skip("this IS the run on the test build")
     env = dict(os.environ, NFP_TEST_LIB="libnfp_hip_poison.so")
     sel = ("match_the_oracle or reference_golden or bf16_storage or full_chip or fused_pooling_tail_on_large_maps "
-           "or dissimilarity or tall_map or pooled_nfp")
+           "or dissimilarity or tall_map or pooled_nfp or class_default")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-m", "gpu", "-k", sel,
                         "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=2400)
     tail = r.stdout[-3000:] + r.stderr[-1000:]
@@ -293,6 +314,44 @@ def test_fused_pooling_tail_on_large_maps(B, C, H, W, R, meas, layout, dtype):
     assert rel_err(gx.float().cpu().numpy(), gref) <= tol_g
 
 
+@pytest.mark.parametrize("name", ["pool_ms_cos_112x112x16", "pool_ms_cos_56x56x24", "pool_ms_cos_14x14x112", "pool_l2_k5_28x28x40"])
+@pytest.mark.parametrize("layout", ["nchw", "nhwc"])
+def test_pooled_nfp_matches_reference_golden(name, layout):
+    """F.adaptive_avg_pool2d(NFPPooling(feat), 1) and its input gradient as the REAL reference computes them
+    (models/texture_pooling.py:251-252, 320-321; fixtures by tests/golden/make_golden.py) against nfp_pooled — the pooled
+    half of the fused tail alone: no GAP(x) sums (gap = NULL in the C ABI), and under no_grad no map stores either; the
+    pooled values are bitwise those of the full fused tail."""
+    import cases as K
+    from conftest import load_golden
+    from test_oracle_golden import assert_pooled_matches_golden
+    from neighbour_feature_pooling_amd import NFPPooling, _abi, nfp_pool, nfp_pooled
+    dev = torch.device("cuda:0")
+    c = K.POOL_BY_NAME[name]
+    g = load_golden(name)
+    m = NFPPooling(c["shape"][1], **c["ctor"])
+    x = torch.from_numpy(K.make_input(c)).to(dev)
+    if layout == "nhwc":
+        x = x.contiguous(memory_format=torch.channels_last)
+    x.requires_grad_(True)
+    L = _abi.load()
+    n0 = L.nfp_launch_count()
+    y = nfp_pooled(x, m.config)
+    fv = L.nfp_last_variant().decode()
+    gy = torch.from_numpy(K.make_pool_grad(c, y.shape[1])).to(dev)
+    gx, = torch.autograd.grad(y, x, gy)
+    torch.cuda.synchronize()
+    bv = L.nfp_last_variant().decode()
+    big = c["shape"][2] * c["shape"][3] > 512
+    assert L.nfp_launch_count() == n0 + (3 if big else 2)
+    assert ",pool>" in fv and ",pool>" in bv and fv.startswith("fwd_tile<" if big else "fwd_band<"), (fv, bv)
+    assert_pooled_matches_golden(y.detach().cpu().numpy(), gx.cpu().numpy(), g, TOL, 2 * TOL)
+    with torch.no_grad():
+        y0 = nfp_pooled(x, m.config)          # no map stores
+        gap1, y1 = nfp_pool(x, m.config)      # the full tail
+    assert torch.equal(y0, y) and torch.equal(y1, y)
+    assert rel_err(gap1.cpu().numpy(), x.detach().mean((2, 3)).cpu().numpy()) <= TOL
+
+
 def test_multistage_network_train_step_runs_on_the_large_map_kernels():
     """models.MultiStageNFPNet (texture_pooling.py:211-268) at 224x224: the three maps above 512 pixels are served by the
     pooled row-band kernels (fwd_tile<...,pool> + pool_fold, bwd_tile<...,pool>), the two small ones by the table kernels;
@@ -308,8 +367,9 @@ def test_multistage_network_train_step_runs_on_the_large_map_kernels():
     import neighbour_feature_pooling_amd.functional as Fn
     orig = Fn.nfp_pool
 
-    def spy(t, cfg):
-        r = orig(t, cfg)
+    def spy(t, cfg, want_gap=True):
+        assert not want_gap, "MultiStageNFPNet consumes the pooled maps alone (texture_pooling.py:251-252)"
+        r = orig(t, cfg, want_gap)
         seen.append((tuple(t.shape[1:]), L.nfp_last_variant().decode()))
         return r
     Fn.nfp_pool = spy
