@@ -8,7 +8,7 @@ sys.path.insert(0, ROOT)
 import torch
 from bench import time_kernel_graph
 from neighbour_feature_pooling_amd import NFPPooling, MultiRadiusNFPPooling, _abi
-from neighbour_feature_pooling_amd.functional import nfp_pool
+from neighbour_feature_pooling_amd.functional import nfp_pool, nfp_pooled
 
 dev = torch.device("cuda", 0)
 s = torch.cuda.Stream()
@@ -48,6 +48,14 @@ for shape, dt, cl, R, meas in (((64, 512, 7, 7), torch.float32, False, 1, "cosin
     tag = f"{list(shape)} {str(dt).split('.')[-1]} {'nhwc' if cl else 'nchw'} k={2 * R + 1} {meas}"
     case(tag + " | fused pooling tail", lambda: nfp_pool(x, m.config), x,
          lambda o: tuple(torch.randn_like(v) for v in o))
+    # round 4: the pooled maps ALONE (texture_pooling.py:251-252: no GAP(x)); and without a gradient to follow (no map stores)
+    case(tag + " | pooled NFP only (nfp_pooled)", lambda: (nfp_pooled(x, m.config),), x, lambda o: tuple(torch.randn_like(v) for v in o))
+    with torch.no_grad(), torch.cuda.stream(s):
+        t0 = time_kernel_graph(lambda: nfp_pooled(x, m.config), 50 if x.numel() < (1 << 24) else 10, s)
+    print(json.dumps({"case": tag + " | pooled NFP only, no_grad (no map stores)", "fwd_us": round(t0, 2), "fwd": L.nfp_last_variant().decode()}))
+    with torch.cuda.stream(s):
+        t1 = time_kernel_graph(lambda: m(x), 50 if x.numel() < (1 << 24) else 10, s)
+    print(json.dumps({"case": tag + " | plain NFP forward (maps only)", "fwd_us": round(t1, 2), "fwd": L.nfp_last_variant().decode()}))
     case(tag + " | x.mean + nfp + mean (what it replaces)",
          lambda: (x.float().mean((2, 3)), m(x).float().mean((2, 3))), x, lambda o: tuple(torch.randn_like(v) for v in o))
 x = torch.randn(64, 512, 7, 7, device=dev, requires_grad=True)
