@@ -87,10 +87,11 @@ typedef struct nfp_desc {
                                 images are dense but spaced apart (ViT tokens behind a class
                                 token, texture_pooling.py:181-188) is read in place and still
                                 gets a dense gradient                                       */
-  const void* ws;            /* DEVICE pointer to the descriptor's constant tables, filled by
+  const void* ws;            /* DEVICE pointer to the descriptor's workspace (constant tables +
+                                the pooled tail's arrival counters), filled by
                                 nfp_workspace_init, or NULL.  The hot-path kernels (stride 1,
-                                pad = R, cosine / L2) read their index maps from it; without it
-                                the call is served by the general kernels                   */
+                                pad = R) read their index maps from it; without it the call is
+                                served by the general kernels                               */
   int32_t inner_R;           /* 0, or 1 with R = 2: ALSO produce the maps of radius 1 (padding 1)
                                 from the same pass — models/nfp_heads.py:80-118 concatenates
                                 NFP(R=1, padding=1) and NFP(R=2, padding=2) of one feature map.
@@ -104,14 +105,21 @@ int nfp_abi_version(void);
 const char* nfp_last_error(void);
 
 /*
- * Constant tables of a descriptor.  What the reference re-derives inside every conv call — which input pixel each
- * kernel tap reads under the padding mode (nn.Conv2d's padding_mode, nfp.py:42-58) — depends only on
- * (H, W, R, pad, stride, dilation, pad_mode), not on the batch, the channels or the data.  The hot-path kernels read
- * it from a table instead of recomputing it per launch:
- *   bytes = nfp_workspace_bytes(d)        0 = this descriptor has no table-driven kernels
+ * Workspace of a descriptor: what the kernels keep between launches.  Two parts:
+ *  - constant tables.  What the reference re-derives inside every conv call — which input pixel each kernel tap reads
+ *    under the padding mode (nn.Conv2d's padding_mode, nfp.py:42-58) — depends only on (H, W, R, pad, stride, dilation,
+ *    pad_mode), not on the batch, the channels or the data.  The hot-path kernels for maps of up to 512 pixels read it
+ *    from a table instead of recomputing it per launch;
+ *  - (ABI 6) one arrival counter per image for the fused pooling tail with several row bands per image: the band that
+ *    finishes last adds up every band's share of the pooled sums inside the same launch (no second launch).  The
+ *    counters are zero between launches; ONE nfp_pool_forward at a time may use a workspace — launches on one stream are
+ *    ordered, a second stream needs a workspace of its own.
+ *   bytes = nfp_workspace_bytes(d)        0 = this descriptor has neither (it is served without a workspace)
  *   nfp_workspace_init(d, ws, stream)     enqueue the fill of `ws` (>= bytes, 16-byte aligned, caller-owned)
  * then set d->ws = ws for nfp_forward / nfp_backward / nfp_pool_*.  One buffer serves every descriptor that
- * differs only in B, C, measure, similarity, dtype, strides, p, eps (the tables do not depend on them).
+ * differs only in B, C, measure, similarity, dtype, strides, p, eps (the tables do not depend on them).  Without it
+ * (d->ws = NULL) every call is still served: maps of up to 512 pixels by the general kernels, the pooled tail by one
+ * band per image or a second, tiny launch.
  */
 int64_t nfp_workspace_bytes(const nfp_desc* d);
 int nfp_workspace_init(const nfp_desc* d, void* ws, void* hip_stream);

@@ -16,6 +16,7 @@ MEASURES = ["norm", "cosine", "dot", "rmse", "geman", "attention", "emd", "canbe
 MEASURE_ALIASES = {"sharpened_cosine": "scs"}
 PAD_MODES = ["zeros", "reflect", "replicate", "circular"]
 F32, BF16 = 0, 1
+TICKET_BYTES = 4096 * 4       # the arrival counters at the head of a workspace (csrc/nfp_common.h: kTicketBytes)
 
 EXPORTS = ["nfp_abi_version", "nfp_last_error", "nfp_output_shape", "nfp_saved_floats", "nfp_forward",
            "nfp_backward", "nfp_pool_supported", "nfp_pool_saved_floats", "nfp_pool_forward", "nfp_pool_backward", "nfp_launch_count",

@@ -63,7 +63,8 @@ struct FoffQ {
 template <int R, int M, bool BF, bool NHWC, bool POOL = false, bool VAR = false>
 __global__ void __launch_bounds__(1024) fwd_band(const KP g, const void* __restrict__ x, void* __restrict__ out,
                                                  float* __restrict__ saved, const unsigned char* __restrict__ ws,
-                                                 int rb, float* __restrict__ gap, float* __restrict__ nfpm) {
+                                                 int rb, float* __restrict__ gap, float* __restrict__ nfpm,
+                                                 float* __restrict__ part) {
   constexpr int N = Win<R>::N, NF = Win<R>::NF;
   constexpr int ES = BF ? 2 : 4;
   extern __shared__ __attribute__((aligned(16))) float4 lds4[];
@@ -195,12 +196,12 @@ __global__ void __launch_bounds__(1024) fwd_band(const KP g, const void* __restr
       // pixels p0 + part, p0 + part + 4, ...; joined by a fixed xor tree.  One band per image: the mean goes straight to
       // gap[b][c]; several bands: the band's sum goes to its row of the scratch (pool_fold joins the bands in order).
       const int nbands = gridDim.y;
-      float* gdst = nbands == 1 ? gap + (long long)b * g.C : gap + ((long long)b * nbands + band) * (g.C + N);
+      float* gdst = nbands == 1 ? gap + (long long)b * g.C : part + ((long long)b * nbands + band) * (g.C + N);
       const float gscale = nbands == 1 ? g.invP : 1.f;
       for (int i0 = 0; i0 < ncq * 4; i0 += T) {
-        const int i = i0 + t, cq = min(i >> 2, ncq - 1), part = i & 3;
+        const int i = i0 + t, cq = min(i >> 2, ncq - 1), quarter = i & 3;   // (which quarter of the pixels this lane sums)
         float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int pp = p0 + part; pp < po; pp += 4) {
+        for (int pp = p0 + quarter; pp < po; pp += 4) {
           const float4 v = slab[cq * Ppb + swz(pp) - base];
           s4.x += v.x;
           s4.y += v.y;
@@ -211,8 +212,13 @@ __global__ void __launch_bounds__(1024) fwd_band(const KP g, const void* __restr
         s4.y = group_sum(s4.y, 4);
         s4.z = group_sum(s4.z, 4);
         s4.w = group_sum(s4.w, 4);
-        if (i < ncq * 4 && part == 0)
-          *(float4*)(gdst + c0 + 4 * cq) = make_float4(s4.x * gscale, s4.y * gscale, s4.z * gscale, s4.w * gscale);
+        if (i < ncq * 4 && quarter == 0) {
+          const float4 gv = make_float4(s4.x * gscale, s4.y * gscale, s4.z * gscale, s4.w * gscale);
+          if (nbands == 1)
+            *(float4*)(gdst + c0 + 4 * cq) = gv;
+          else   // (a scratch row another workgroup may fold: written through — nfp_common.h::pool_last_band)
+            pool_store4(pool_rsrc(gdst, g.C + N), c0 + 4 * cq, gv);
+        }
       }
     }
     if (active) {
@@ -311,8 +317,15 @@ __global__ void __launch_bounds__(1024) fwd_band(const KP g, const void* __restr
         if (nbands == 1)
           nfpm[(long long)b * N + n] = sacc * g.invP;
         else
-          gap[((long long)b * nbands + band) * (g.C + N) + g.C + n] = sacc;
+          pool_store1(pool_rsrc(part + ((long long)b * nbands + band) * (g.C + N), g.C + N), g.C + n, sacc);
       }
+    }
+    // several bands and a ticket counter: the band that arrives last folds all of them (nfp_common.h::pool_last_band);
+    // without counters (no workspace) the caller launches pool_fold
+    if (nbands > 1 && g.tickets != nullptr) {
+      if (pool_last_band(g.tickets + b, nbands, (int*)lds4, t == 0))
+        pool_fold_image(part + (long long)b * nbands * (g.C + N), nbands, g.C, N, g.invP,
+                        g.pool_gap ? gap + (long long)b * g.C : nullptr, nfpm + (long long)b * N, t, T);
     }
   }
   NFP_STAMP(5);

@@ -54,7 +54,79 @@ struct KP {
   // the maps themselves — pool_map = 0 skips their stores.
   int pool_gap, pool_map;
   int pf;   // fwd_band: several channel chunks — the next chunk's loads are issued under the current chunk's sums
+  unsigned int* tickets;   // fused pooling tail, several row bands per image: one arrival counter per image (the first
+                           // kTicketBytes of the descriptor's workspace, zero between launches) or null — see pool_last_band
 };
+constexpr int kTicketWords = 4096;              // (batches beyond it: no counters — make_kp)
+constexpr int kTicketBytes = kTicketWords * 4;
+
+// ---- single-launch combine of the row bands' pooled sums (round 4) -----------------------------------------------------
+// The pooled outputs are sums over the whole image; with several workgroups (row bands) per image each band writes its
+// share to a scratch row and SOMEBODY has to add the rows up.  Round 3 did that with a second launch (pool_fold: +3 us
+// at the sizes where the pooled forward itself takes 6-30 us).  Here the band that ARRIVES LAST does it: every band,
+// its scratch row written through to memory, draws a ticket from the image's counter; the band that draws
+// nb - 1 knows every other row is complete and folds ALL rows in band order — so the result does not depend
+// on which band was last: bitwise reproducible.  It then puts the counter back to 0 for the next launch.
+// The counters live in the descriptor's workspace (nfp_workspace_init zeroes them): ONE pooled launch at a time per
+// workspace — launches on one stream are ordered; a second stream needs a workspace of its own (include/nfp.h).
+// Protocol (MI355X guide, "in-launch split-K reduction", the write-through form): the scratch rows are written with sc1
+// (write-through) stores, so no release fence is needed — an agent-scope release writes back EVERY dirty line of the L2,
+// and these kernels have just dirtied megabytes of maps: the first cut with fences ran 3x slower than two launches
+// (profiles/r04_d_…) — every wave s_waitcnt vmcnt(0) -> barrier -> one lane: relaxed agent-scope fetch_add; the last
+// arriver reads the rows with sc1 loads (no acquire fence either: pool_fold_image).
+// `flag`: one LDS word nobody else uses between the two barriers below.  Returns (in every thread) whether this
+// workgroup is the image's last.
+__device__ __forceinline__ bool pool_last_band(unsigned int* ticket, int nb, int* flag, bool thread0) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (thread0) {
+    const unsigned int old = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool last = old == (unsigned int)(nb - 1);
+    if (last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (all nb arrivals are in)
+    *flag = last ? 1 : 0;
+  }
+  __syncthreads();
+  return *flag != 0;
+}
+// write-through stores / cache-bypassing loads of the scratch rows (buffer instructions with sc1)
+typedef unsigned int pool_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t pool_rsrc(const float* base, long long floats) {
+  const long long bytes = floats * 4;
+  return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)(bytes > 0x7ffffff0LL ? 0x7ffffff0LL : bytes), 0x00020000);
+}
+__device__ __forceinline__ void pool_store1(__amdgpu_buffer_rsrc_t r, int i, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, i * 4, 0, 16);
+}
+__device__ __forceinline__ void pool_store4(__amdgpu_buffer_rsrc_t r, int i, float4 v) {
+  const pool_u32x4 u = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+  __builtin_amdgcn_raw_buffer_store_b128(u, r, i * 4, 0, 16);
+}
+__device__ __forceinline__ float pool_load1(__amdgpu_buffer_rsrc_t r, int i) {
+  return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, i * 4, 0, 16));
+}
+// gap[c] = (sum over the image's `rows` scratch rows of row[c]) / P, nfpm[n] likewise from row[C + n]: rows in order,
+// eight loads in flight at a time.  gap == nullptr: the bands wrote no channel sums.
+__device__ __forceinline__ void pool_fold_image(const float* __restrict__ rows0, int rows, int C, int N, float invP,
+                                                float* __restrict__ gap_b, float* __restrict__ nfpm_b, int tid, int nthreads) {
+  const int CN = C + N;
+  const __amdgpu_buffer_rsrc_t pr = pool_rsrc(rows0, (long long)rows * CN);
+  for (int k = (gap_b != nullptr ? 0 : C) + tid; k < CN; k += nthreads) {
+    float s = 0.f;
+    int j = 0;
+    for (; j + 8 <= rows; j += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = pool_load1(pr, (j + u) * CN + k);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; j < rows; ++j) s += pool_load1(pr, j * CN + k);
+    if (k < C)
+      gap_b[k] = s * invP;
+    else
+      nfpm_b[k - C] = s * invP;
+  }
+}
 __device__ __forceinline__ float unit_or(const KP& g, float v) { return fmaf(v, g.nuf, g.uf); }
 // GFC (nfp.py:265-276): num / (|a| |b| + eps).  Its gradient has the shape of cosine's — per pair {g', g' f}, a cross
 // weight and a pull on |x| — with other post-factors, so it rides on the product kernels too (round 3).  With the

@@ -473,18 +473,22 @@ __global__ void __launch_bounds__(GEMM ? 1024 : kBwdThreads) bwd_fast(const KP g
   const int P = g.P;
   // LDS: Wt | Dt | ipn | dfn (live to the end) | pair values | x slab.  The slab lies OVER the pair values (dead
   // once Wt is built) when both do not fit side by side (g.early == 0).
+  // Matrix-core variant (round 4): Dt is dead once the diagonal is folded (A3), so it sits BEHIND the tables that live to
+  // the end and the GEMM's operand images are laid over it as well: Wt | ipn | dfn | Dt | pair values.  19.6 KB more for
+  // Wd at config 5's shape: three row tiles per round instead of two, three rounds of zero / scatter / multiply instead
+  // of four (2.2 us each: profiles/r02_j_matrix_core_backward_ab.txt).
   float* Wt = (float*)lds4;        // [P][K2] gathered weights
-  float* Dt = Wt + P * K2;         // [P][K2] diagonal terms collected per slot
-  float* ipn = Dt + P * K2;        // [P] 1 / max(|x_p|, eps)
+  float* ipn = GEMM ? Wt + P * K2 : Wt + 2 * P * K2;   // [P] 1 / max(|x_p|, eps)
   float* dfn = ipn + P;            // [P] -1 / (|x_p| max(|x_p|, eps)), 0 where |x_p| = 0
-  float4* pv4 = lds4 + ((2 * P * K2 + 2 * P + 3) >> 2);
+  float* Dt = GEMM ? (float*)(lds4 + ((P * K2 + 2 * P + 3) >> 2)) : Wt + P * K2;   // [P][K2] diagonal terms collected per slot
+  float4* pv4 = GEMM ? (float4*)Dt + ((P * K2 + 3) >> 2) : lds4 + ((2 * P * K2 + 2 * P + 3) >> 2);
   float2* AD = (float2*)pv4;       // cosine: [N*P] {sg, sg*s} of pair o = n*P + p
   float* CC = (float*)pv4;         // L2:     [N*P] c = -+g/d
   float4* slab = g.early ? pv4 + (((M == NFP_COSINE ? 2 : 1) * N * P + 3) >> 2) : pv4;  // [Cc/4][P]
   const int b = blockIdx.x, t = threadIdx.x, T = blockDim.x;
   const int cb0 = blockIdx.y * g.Cwg, cb1 = min(g.C, cb0 + g.Cwg);
-  // matrix-core variant: Xt over the pair values (dead once Wt is built), Wd behind it
-  uint4* gemm_Xt = (uint4*)pv4;
+  // matrix-core variant: Xt over Dt and the pair values (dead once Wt is built and folded), Wd behind it
+  uint4* gemm_Xt = (uint4*)Dt;
   uint4* gemm_Wd = gemm_Xt + (long long)(cb1 - cb0) * gemm_xq(P);
   const uint16_t* x16 = (const uint16_t*)x + (long long)b * g.sB;
   // fused pooling tail, matrix-core variant: grad(GAP(x)) / P of this workgroup's channels goes to LDS behind Wd (read
@@ -650,9 +654,16 @@ __global__ void __launch_bounds__(GEMM ? 1024 : kBwdThreads) bwd_fast(const KP g
     ipn[t] = fmaf(nrm, g.gf, ip * g.ngf);                                     // (GFC: the norm itself — nfp_common.h::cross_f)
     dfn[t] = nrm > 0.f ? -fmaf(1.f, g.gf, g.nuf * ip * g.ngf) * __builtin_amdgcn_rcpf(nrm) : 0.f;
   }
-  if constexpr (SYM) {  // slots before the centre whose pixel lies outside the image keep this 0 (Wt and Dt are adjacent)
-    for (int i = t; i < (2 * P * K2) >> 2; i += T) ((float4*)Wt)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (t < ((2 * P * K2) & 3)) Wt[((2 * P * K2) & ~3) + t] = 0.f;
+  if constexpr (SYM) {  // slots before the centre whose pixel lies outside the image keep this 0
+    if constexpr (GEMM) {   // (Wt and Dt apart: see the layout above)
+      for (int i = t; i < P * K2; i += T) {
+        Wt[i] = 0.f;
+        Dt[i] = 0.f;
+      }
+    } else {                // (Wt and Dt are adjacent)
+      for (int i = t; i < (2 * P * K2) >> 2; i += T) ((float4*)Wt)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (t < ((2 * P * K2) & 3)) Wt[((2 * P * K2) & ~3) + t] = 0.f;
+    }
   }
   if constexpr (POOL && GEMM) {
     const int ncw = cb1 - cb0;

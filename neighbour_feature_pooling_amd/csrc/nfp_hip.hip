@@ -9,6 +9,7 @@
 #include "nfp_gather.h"
 #include "nfp_mfma.h"
 #include "nfp_direct.h"
+#include "nfp_gemm2.h"
 
 using namespace nfp;
 using namespace nfp_host;
@@ -65,7 +66,10 @@ int make_kp(const nfp_desc* d, KP* g) {
   g->p = d->measure == NFP_EMD ? 1.f : d->p; g->eps = d->eps; g->q_scs = d->q_scs;
   g->sB = d->sxB; g->sC = d->sxC; g->sH = d->sxH; g->sW = d->sxW;
   g->gB = d->sgB != 0 ? d->sgB : d->sxB;
-  g->ws = (const unsigned char*)d->ws;
+  // the descriptor's workspace: kTicketBytes of per-image arrival counters (pooled kernels with several row bands per
+  // image: nfp_common.h::pool_last_band), then — for the table kernels' geometries — the constant tables
+  g->tickets = (g_sw.pool_ticket.load(std::memory_order_relaxed) && d->B <= kTicketWords) ? (unsigned int*)d->ws : nullptr;
+  g->ws = d->ws != nullptr ? (const unsigned char*)d->ws + kTicketBytes : nullptr;
   g->contig = (d->sxW == 1 && d->sxH == d->W && d->sxC == (int64_t)d->H * d->W) ? 1 : 0;
   g->invP = 1.0f / (float)g->P;
   g->invW = 1.0f / (float)g->W;
@@ -85,6 +89,9 @@ int make_kp(const nfp_desc* d, KP* g) {
   g->pool_gap = g->pool_map = 1;
   g->d2s = d->measure == NFP_RMSE ? 1.0f / (float)d->C : 1.0f;
   g->zero0 = d->measure == NFP_RMSE ? 0 : 1;
+  if (!(g->stride == 1 && g->dil == 1 && g->pad == g->R && g->mode != NFP_PAD_CIRCULAR && (g->R == 1 || g->R == 2) &&
+        g->P <= kBwdThreads && g->P >= 4))
+    g->ws = nullptr;   // (not a table geometry — fast_geometry below: its workspace holds the counters alone)
   // index arithmetic of the general kernels: coordinates in 15 bits, pair indices in 31
   if (d->H > 32767 || d->W > 32767 || (int64_t)g->P > (1 << 26) || (int64_t)g->N * g->O >= (1LL << 31) || d->B > 65535)
     return fail(NFP_E_UNSUPPORTED, "feature map [%d,%d,%d,%d] with k = %d exceeds the index range of the kernels", d->B,
@@ -392,7 +399,9 @@ int launch_fwd_band_t(KP g, const void* x, void* out, float* saved, hipStream_t 
 #ifndef NFP_POOL_BANDS
 #define NFP_POOL_BANDS 0
 #endif
-  if (POOL && (part == nullptr || !NFP_POOL_BANDS)) nb = 1;
+  // Round 4: with the workspace's arrival counters the last band to finish folds them all inside the SAME launch
+  // (nfp_common.h::pool_last_band): the bands come back.  Without counters: one band, as before.
+  if (POOL && (part == nullptr || !(NFP_POOL_BANDS || g.tickets != nullptr))) nb = 1;
   const int rb = (g.H + nb - 1) / nb;
   nb = (g.H + rb - 1) / rb;
   const int psm = std::min(g.P, (rb + g.R) * g.W);          // most pixels a band stages
@@ -440,9 +449,9 @@ int launch_fwd_band_t(KP g, const void* x, void* out, float* saved, hipStream_t 
   // (pooled, several bands: the bands' partial sums go to `part`; the caller folds them — pool_forward_rm)
   if (g.unit || g.gfc || g.d2s != 1.f)   // DotProduct / GFC / RMSE: the finalize with the run-time constants
     return launch("fwd_band", fwd_band<R, M, BF, NHWC, POOL, true>, dim3(g.B, nb), dim3(T), lds, st, g, x, out, saved, g.ws,
-                  rb, (POOL && nb > 1) ? part : gap, nfpm);
+                  rb, gap, nfpm, part);
   return launch("fwd_band", fwd_band<R, M, BF, NHWC, POOL, false>, dim3(g.B, nb), dim3(T), lds, st, g, x, out, saved, g.ws,
-                rb, (POOL && nb > 1) ? part : gap, nfpm);
+                rb, gap, nfpm, part);
 }
 
 template <int R, int M>
@@ -554,6 +563,37 @@ int launch_bwd_gemm_t(KP g, const void* x, const void* go, const void* out, cons
   if (S < 1) S = 1;
   g.Cwg = ((g.C / 32 + S - 1) / S) * 32;
   S = (g.C + g.Cwg - 1) / g.Cwg;
+  // Round 4: phase A without tables, one thread per padded position (nfp_gemm2.h) — while every position has a thread and
+  // its planes fit beside the window table.  (GFC keeps the table-driven phase A: one instantiation set fewer.)
+  if constexpr (R != 12) {
+    const int npu2 = (g.H + 2 * R) * (g.W + 2 * R);
+    if (g_sw.gemm2.load(std::memory_order_relaxed) && !g.gfc && npu2 <= 1024 && !(!NHWC && (g.P & 3) && S < 2)) {
+      KP h = g;
+      h.Cc = h.Cwg;
+      const int band2 = R * g.W + R, KW2 = (32 + 2 * band2 + 30) >> 4;
+      const size_t xq2 = (size_t)((((g.P + 15) >> 4 << 1) + 1) | 1), wq2 = (size_t)((2 * KW2 + 1) | 1);
+      const int nt2 = (g.P + 31) / 32;
+      const size_t wtb = (((size_t)g.P * K2 + 3) & ~(size_t)3) * 4, planes = (size_t)nfp::gemm2_plane_floats<R>(g.H, g.W) * 4;
+      const size_t xt2 = (size_t)h.Cwg * xq2 * 16, wd2 = (size_t)2 * 32 * wq2 * 16, ggb2 = POOL ? (size_t)h.Cwg * 4 : 0;
+      int rt2 = wtb + xt2 + ggb2 < (size_t)kLdsMax ? (int)(((size_t)kLdsMax - wtb - xt2 - ggb2) / wd2) : 0;
+      rt2 = std::min(rt2, nt2);
+      if (rt2 >= 2 && rt2 < nt2) rt2 = (nt2 + ((nt2 + rt2 - 1) / rt2) - 1) / ((nt2 + rt2 - 1) / rt2);
+      // (the block's grad(GAP) values are written during phase A: they must lie beyond its planes)
+      const bool gg_clear = !POOL || xt2 + (size_t)rt2 * wd2 >= planes;
+      if (rt2 >= std::min(2, nt2) && gg_clear) {
+        h.Tc = rt2;
+        h.early = 0;
+        const size_t lds2 = wtb + std::max(planes, xt2 + (size_t)rt2 * wd2 + ggb2);
+        h.Ow = (int)(lds2 / 4);
+        if (lds2 <= (size_t)kLdsMax) {
+          snprintf(g_variant, sizeof(g_variant), "bwd_gemm2<R%d,%s,bf16,%s,mfma%s>", R, hot_name(g), NHWC ? "nhwc" : "nchw",
+                   POOL ? ",pool" : "");
+          return launch("bwd_gemm2", bwd_gemm2<R, M, NHWC, POOL>, dim3(g.B, S), dim3(1024), lds2, st, h, x, go, out, saved, gx,
+                        ggap, gnfpm);
+        }
+      }
+    }
+  }
   // NCHW rows that are not 8-byte aligned (H*W % 4 != 0) are staged and stored 2 bytes at a time: that only pays
   // while the batch is small enough for the channel split (measured: 7.2 vs 8.4 us at B = 64, 16.1 vs 14.0 at 256)
   if (!NHWC && (g.P & 3) && S < 2) return kNotApplicable;
@@ -572,7 +612,10 @@ int launch_bwd_gemm_t(KP g, const void* x, const void* go, const void* out, cons
   const size_t xq = (size_t)((((g.P + 15) >> 4 << 1) + 1) | 1), wq = (size_t)((2 * KW + 1) | 1);
   // row tiles whose densified weights sit in LDS together (fewer rounds of zero / scatter / barrier): all that fit
   const int nt = (g.P + 31) / 32;
-  const size_t xt = (size_t)g.Cwg * xq * 16, wd1 = (size_t)2 * 32 * wq * 16, fixed = bwd_fixed_bytes(g, K2);
+  // LDS of this variant (nfp_fast.h::bwd_fast, GEMM): Wt | ipn | dfn live to the end; Dt and the pair values are dead once
+  // the diagonal is folded — the operand images lie over both
+  const size_t xt = (size_t)g.Cwg * xq * 16, wd1 = (size_t)2 * 32 * wq * 16;
+  const size_t fixed = ((size_t)(g.P * K2 + 2 * g.P) * 4 + 15) & ~(size_t)15, dtb = ((size_t)g.P * K2 * 4 + 15) & ~(size_t)15;
   const size_t ggb = POOL ? (size_t)g.Cwg * 4 : 0;   // grad(GAP(x)) of the block, staged behind Wd
   int rt = fixed + xt + ggb < (size_t)kLdsMax ? (int)(((size_t)kLdsMax - fixed - xt - ggb) / wd1) : 0;
   rt = std::min(rt, nt);
@@ -580,7 +623,7 @@ int launch_bwd_gemm_t(KP g, const void* x, const void* go, const void* out, cons
   if (rt < std::min(2, nt)) return kNotApplicable;
   g.Tc = rt;
   const size_t images = xt + (size_t)rt * wd1 + ggb;
-  const size_t lds = fixed + std::max(bwd_pair_bytes(g, M, N), images);
+  const size_t lds = fixed + std::max(dtb + bwd_pair_bytes(g, M, N), images);
   g.early = 0;
   if (lds > (size_t)kLdsMax) return kNotApplicable;
   snprintf(g_variant, sizeof(g_variant), "bwd_fast<R%d,%s,bf16,%s,mfma%s>", R, hot_name(g),
@@ -683,7 +726,7 @@ int forward_impl(const nfp_desc* d, const void* x, void* out, float* saved, void
     return rc == kNotApplicable ? fail(NFP_E_UNSUPPORTED, "multi-radius: the map does not fit the hot-path forward") : rc;
   }
   if (g_sw.tile_first.load(std::memory_order_relaxed))
-    if (int rc = tile_forward(g, x, out, saved, st, false, nullptr, nullptr); rc != kNotApplicable) return rc;
+    if (int rc = tile_forward(g, x, out, saved, st, false, nullptr, nullptr, nullptr, nullptr); rc != kNotApplicable) return rc;
   if (fast_ok(g, x, x) && hot_l1(g)) {
     const int rc = g.R == 1 ? launch_fwd_band<1, kNormP1>(g, x, out, saved, st) : launch_fwd_band<2, kNormP1>(g, x, out, saved, st);
     if (rc != kNotApplicable) return rc;
@@ -705,7 +748,7 @@ int forward_impl(const nfp_desc* d, const void* x, void* out, float* saved, void
     if (rc != kNotApplicable) return rc;
   }
   // maps above the table kernels' 512 pixels, or a descriptor without its tables: the row-band kernels (nfp_tile.hip)
-  if (int rc = tile_forward(g, x, out, saved, st, false, nullptr, nullptr); rc != kNotApplicable) return rc;
+  if (int rc = tile_forward(g, x, out, saved, st, false, nullptr, nullptr, nullptr, nullptr); rc != kNotApplicable) return rc;
   switch (g.measure) {
     case NFP_COSINE: return launch_fwd_generic<NFP_COSINE>(g, x, out, saved, st);
     case NFP_NORM:
@@ -837,6 +880,7 @@ int pool_forward_rm(const KP& g, const void* x, void* out_map, float* saved, hip
                    : launch_fwd_band_t<R, M, false, false, true>(g, x, out_map, saved, st, gap, nfpm, part, &nb);
     if (rc == NFP_OK && nb > 1) {
       t_pool_scratch = (long long)g.B * nb * (g.C + g.N);
+      if (g.tickets != nullptr) return rc;   // (the last band to arrive folded them inside the launch)
       strncat(g_variant, "+pool_fold", sizeof(g_variant) - strlen(g_variant) - 1);
       return tile_pool_fold(g, part, gap, nfpm, nb, st);
     }
@@ -847,8 +891,9 @@ int pool_forward_rm(const KP& g, const void* x, void* out_map, float* saved, hip
   if (saved == nullptr) return fail(NFP_E_INVALID, "fused pooling tail on this map needs the scratch of nfp_pool_saved_floats");
   float* part = saved + (long long)stats_of(g.measure) * g.B * g.P;
   int nb = 0;
-  if (int rc = tile_forward(g, x, out_map, saved, st, true, part, &nb); rc != NFP_OK) return rc;
+  if (int rc = tile_forward(g, x, out_map, saved, st, true, part, &nb, gap, nfpm); rc != NFP_OK) return rc;
   t_pool_scratch = (long long)g.B * nb * (g.C + g.N);
+  if (g.tickets != nullptr) return NFP_OK;   // (single launch: the last band to arrive folds, nfp_common.h::pool_last_band)
   strncat(g_variant, "+pool_fold", sizeof(g_variant) - strlen(g_variant) - 1);
   return tile_pool_fold(g, part, gap, nfpm, nb, st);
 }
@@ -923,10 +968,14 @@ static int max_links(const KP& g) {
 int64_t nfp_workspace_bytes(const nfp_desc* d) {
   KP g;
   if (make_kp(d, &g)) return -1;
-  if (!fast_geometry(g)) return 0;
+  if (!fast_geometry(g)) {
+    // no tables; "same" maps the row-band kernels serve still get the arrival counters of their fused pooling tail
+    return (g.stride == 1 && g.dil == 1 && g.pad == g.R && g.mode != NFP_PAD_CIRCULAR && (g.R == 1 || g.R == 2) && g.rs != 12)
+               ? (int64_t)kTicketBytes : 0;
+  }
   const WsLayout L = ws_layout(g.P, g.rs, g.mode);
   if (max_links(g) > L.LW) return 0;
-  return (int64_t)L.bytes;
+  return (int64_t)kTicketBytes + (int64_t)L.bytes;
 }
 
 int nfp_workspace_init(const nfp_desc* d, void* ws, void* hip_stream) {
@@ -935,10 +984,14 @@ int nfp_workspace_init(const nfp_desc* d, void* ws, void* hip_stream) {
   if (nfp_workspace_bytes(d) <= 0) return fail(NFP_E_UNSUPPORTED, "this descriptor has no workspace tables");
   if (!ws || ((uintptr_t)ws & 15)) return fail(NFP_E_INVALID, "workspace pointer must be non-null and 16-byte aligned");
   hipStream_t st = (hipStream_t)hip_stream;
+  if (!t_dry)   // the arrival counters of the pooled kernels: zero between launches (nfp_common.h::pool_last_band)
+    if (int rc = hip_ok(hipMemsetAsync(ws, 0, kTicketBytes, st), "zero the workspace's counters")) return rc;
+  if (!fast_geometry(g)) return NFP_OK;   // (no tables for this geometry)
+  unsigned char* tables = (unsigned char*)ws + kTicketBytes;
   const int items = g.P * g.k * g.k, blocks = std::min(64, (items + 255) / 256);
-  if (g.rs == 12) return launch("#fill_workspace", fill_workspace<12>, dim3(blocks), dim3(256), 0, st, g, (unsigned char*)ws);
-  return g.R == 1 ? launch("#fill_workspace", fill_workspace<1>, dim3(blocks), dim3(256), 0, st, g, (unsigned char*)ws)
-                  : launch("#fill_workspace", fill_workspace<2>, dim3(blocks), dim3(256), 0, st, g, (unsigned char*)ws);
+  if (g.rs == 12) return launch("#fill_workspace", fill_workspace<12>, dim3(blocks), dim3(256), 0, st, g, tables);
+  return g.R == 1 ? launch("#fill_workspace", fill_workspace<1>, dim3(blocks), dim3(256), 0, st, g, tables)
+                  : launch("#fill_workspace", fill_workspace<2>, dim3(blocks), dim3(256), 0, st, g, tables);
 }
 
 int nfp_forward(const nfp_desc* d, const void* x, void* out, float* saved, void* hip_stream) {

@@ -42,6 +42,11 @@ struct Switches {
   std::atomic<int> fwd_scalar{0}, bwd_atomic{0}, bwd_bands{0}, force_generic{0}, mfma{1}, tile_first{0};
   std::atomic<int> tile_wgs{0}, tile_lds_kb{0}, tile_cap{0};   // A/B overrides of the row-band launchers' constants (0: built-in)
   std::atomic<int> tile_max_grid{0};                           // (tests: a smaller launch-splitting threshold)
+  std::atomic<int> pool_ticket{0};   // A/B: fused pooling tail, several row bands per image combined inside ONE launch by the
+                                     // band that arrives last (nfp_common.h::pool_last_band).  Measured slower than what it
+                                     // replaces (profiles/r04_e_…: 8.7 vs 6.9 us at the headline shape, 103 vs 91 us at
+                                     // [256,16,112,112]): off by default
+  std::atomic<int> gemm2{1};         // A/B: the matrix-core backward with the table-free phase A (nfp_gemm2.h)
 };
 inline Switches g_sw;
 #ifndef NFP_MFMA_DEFAULT
@@ -56,6 +61,8 @@ inline void read_env() {
   g_sw.bwd_atomic = flag("NFP_BWD_ATOMIC", 0);
   g_sw.force_generic = flag("NFP_FORCE_GENERIC", 0);
   g_sw.mfma = flag("NFP_MFMA", NFP_MFMA_DEFAULT);
+  g_sw.pool_ticket = flag("NFP_POOL_TICKET", 0);
+  g_sw.gemm2 = flag("NFP_GEMM2", 1);
   g_sw.tile_first = flag("NFP_TILE_FIRST", 0);   // A/B: the row-band kernels of nfp_tile.h also for maps the table kernels serve
   auto num = [](const char* name) {
     const char* e = getenv(name);
@@ -173,7 +180,8 @@ inline int even_groups(int ncq, int gmax) {
 // Each returns NFP_OK, kNotApplicable (this descriptor is not theirs / does not fit) or an NFP_E_* code; g_variant names
 // the launch.  pool: the fused nfp_pooling tail (part = scratch for the bands' partial sums; *nb = bands per image).
 bool tile_ok(const KP& g, const void* x, const void* gx);
-int tile_forward(const KP& g, const void* x, void* out, float* saved, hipStream_t st, bool pool, float* part, int* nb);
+int tile_forward(const KP& g, const void* x, void* out, float* saved, hipStream_t st, bool pool, float* part, int* nb,
+                 float* gap, float* nfpm);
 int tile_backward(const KP& g, const void* x, const void* go, const void* out, const float* saved, void* gx, hipStream_t st,
                   bool pool, const float* ggap, const float* gnfpm);
 int tile_pool_fold(const KP& g, const float* part, float* gap, float* nfpm, int nb, hipStream_t st);

@@ -279,7 +279,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 template <int R, int M, bool BF, bool NHWC, bool POOL = false, bool GFC = false>
 __global__ void __launch_bounds__(1024, (R == 1 ? 8 : 4)) fwd_tile(const KP g, const TileGeo tg, const void* __restrict__ x,
                                                  void* __restrict__ out, float* __restrict__ saved,
-                                                 float* __restrict__ part) {
+                                                 float* __restrict__ part, float* __restrict__ gap, float* __restrict__ nfpm) {
   constexpr int N = Win<R>::N, NF = Win<R>::NF;
   constexpr int ES = BF ? 2 : 4;
   extern __shared__ __attribute__((aligned(16))) float4 lds4[];
@@ -327,7 +327,8 @@ __global__ void __launch_bounds__(1024, (R == 1 ? 8 : 4)) fwd_tile(const KP g, c
       // the segment's pixels; one writer per (segment, channel).  pool_fold joins segments and bands in a fixed order.
       const int t = ps.gl + G * v, lane = t & 63, wv = t >> 6, nw = (G * npu) >> 6;
       const int nbp = (bd.y1 - bd.y0) * W, seg = (nbp + kPoolSub - 1) / kPoolSub;
-      float* pb = part + ((long long)b * tg.nb + band) * kPoolSub * (g.C + N) + c0;
+      // (scratch rows another workgroup may fold: written through — nfp_common.h::pool_last_band)
+      const Rsrc pb = pool_rsrc(part + ((long long)b * tg.nb + band) * kPoolSub * (g.C + N), (long long)kPoolSub * (g.C + N));
       if (wv < nw) {
         for (int it = wv; it < ncq * kPoolSub; it += nw) {
           const int cq = it / kPoolSub, sub = it - cq * kPoolSub, hi = min(nbp, (sub + 1) * seg);
@@ -344,7 +345,7 @@ __global__ void __launch_bounds__(1024, (R == 1 ? 8 : 4)) fwd_tile(const KP g, c
           s4.y = wave_sum(s4.y);
           s4.z = wave_sum(s4.z);
           s4.w = wave_sum(s4.w);
-          if (lane == 63) *(float4*)(pb + sub * (g.C + N) + 4 * cq) = s4;
+          if (lane == 63) pool_store4(pb, sub * (g.C + N) + c0 + 4 * cq, s4);
         }
       } else if (nw == 0 && t == 0) {  // (a workgroup below 64 threads: tiny maps, one thread adds them up)
         for (int cq = 0; cq < ncq; ++cq) {
@@ -358,7 +359,7 @@ __global__ void __launch_bounds__(1024, (R == 1 ? 8 : 4)) fwd_tile(const KP g, c
             s4.w += q.w;
           }
           for (int sub = 0; sub < kPoolSub; ++sub)
-            *(float4*)(pb + sub * (g.C + N) + 4 * cq) = sub == 0 ? s4 : make_float4(0.f, 0.f, 0.f, 0.f);
+            pool_store4(pb, sub * (g.C + N) + c0 + 4 * cq, sub == 0 ? s4 : make_float4(0.f, 0.f, 0.f, 0.f));
         }
       }
     }
@@ -461,27 +462,36 @@ __global__ void __launch_bounds__(1024, (R == 1 ? 8 : 4)) fwd_tile(const KP g, c
     __syncthreads();
     const int t = ps.gl + G * v, lane = t & 63, wv = t >> 6, nw = (G * npu) >> 6;
     const int nbp = (bd.y1 - bd.y0) * W, seg = (nbp + kPoolSub - 1) / kPoolSub;
-    float* pb = part + ((long long)b * tg.nb + band) * kPoolSub * (g.C + N) + g.C;
+    const Rsrc pb = pool_rsrc(part + ((long long)b * tg.nb + band) * kPoolSub * (g.C + N), (long long)kPoolSub * (g.C + N));
     if (wv < nw) {
       for (int it = wv; it < N * kPoolSub; it += nw) {
         const int n = it / kPoolSub, sub = it - n * kPoolSub, hi = min(nbp, (sub + 1) * seg);
         float s = 0.f;
         for (int i = sub * seg + lane; i < hi; i += 64) s += vm[n * nbpA + i];
         s = wave_sum(s);
-        if (lane == 63) pb[sub * (g.C + N) + n] = s;
+        if (lane == 63) pool_store1(pb, sub * (g.C + N) + g.C + n, s);
       }
     } else if (nw == 0 && t == 0) {
       for (int n = 0; n < N; ++n) {
         float s = 0.f;
         for (int i = 0; i < nbp; ++i) s += vm[n * nbpA + i];
-        for (int sub = 0; sub < kPoolSub; ++sub) pb[sub * (g.C + N) + n] = sub == 0 ? s : 0.f;
+        for (int sub = 0; sub < kPoolSub; ++sub) pool_store1(pb, sub * (g.C + N) + g.C + n, sub == 0 ? s : 0.f);
       }
+    }
+    // the band that arrives last folds every band's row of the image, in band order (nfp_common.h::pool_last_band);
+    // without counters (a descriptor without its workspace) the caller launches pool_fold
+    if (g.tickets != nullptr) {
+      const int nth = blockDim.x * blockDim.y * blockDim.z;
+      if (pool_last_band(g.tickets + b, tg.nb, (int*)lds4, t == 0))
+        pool_fold_image(part + (long long)b * tg.nb * kPoolSub * (g.C + N), tg.nb * kPoolSub, g.C, N, g.invP,
+                        g.pool_gap ? gap + (long long)b * g.C : nullptr, nfpm + (long long)b * N, t, nth);
     }
   }
   NFP_STAMP(5);
 }
 
 // gap[b][c] = (sum over bands of part[b][band][c]) / P, nfpm[b][n] likewise: the bands in a fixed order
+template <int = 0>
 __global__ void __launch_bounds__(256) pool_fold(const float* __restrict__ part, float* __restrict__ gap,
                                                  float* __restrict__ nfpm, int B, int nb, int C, int N, float invP) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;

@@ -76,7 +76,8 @@ int tile_groups(const KP& g, int nb, int npu, int cap, int cq) {
 }
 
 template <int R, int M, bool BF, bool NHWC, bool POOL = false>
-int launch_fwd_tile_t(KP g, const void* x, void* out, float* saved, hipStream_t st, float* part = nullptr, int* nb_out = nullptr) {
+int launch_fwd_tile_t(KP g, const void* x, void* out, float* saved, hipStream_t st, float* part = nullptr, int* nb_out = nullptr,
+                      float* gap = nullptr, float* nfpm = nullptr) {
   constexpr int NF = Win<R>::NF, N = Win<R>::N;
   const int Wu = g.W + 2 * R;
   for (int attempt = 0; attempt < 2; ++attempt) {
@@ -121,11 +122,13 @@ int launch_fwd_tile_t(KP g, const void* x, void* out, float* saved, hipStream_t 
         void* os = (char*)out + (long long)b0 * N * g.P * es;
         float* ss = saved ? saved + (long long)b0 * g.P : nullptr;
         float* ps = part ? part + (long long)b0 * nb * nfp::kPoolSub * (g.C + N) : nullptr;
+        float* gs_ = gap ? gap + (long long)b0 * g.C : nullptr;
+        float* ns_ = nfpm ? nfpm + (long long)b0 * N : nullptr;
         int rc;
         if (M == NFP_COSINE && g.gfc)
-          rc = launch("fwd_tile", fwd_tile<R, M, BF, NHWC, POOL, M == NFP_COSINE>, grid, block, lds, st, gs, tg, xs, os, ss, ps);
+          rc = launch("fwd_tile", fwd_tile<R, M, BF, NHWC, POOL, M == NFP_COSINE>, grid, block, lds, st, gs, tg, xs, os, ss, ps, gs_, ns_);
         else
-          rc = launch("fwd_tile", fwd_tile<R, M, BF, NHWC, POOL, false>, grid, block, lds, st, gs, tg, xs, os, ss, ps);
+          rc = launch("fwd_tile", fwd_tile<R, M, BF, NHWC, POOL, false>, grid, block, lds, st, gs, tg, xs, os, ss, ps, gs_, ns_);
         if (rc != NFP_OK) return rc;
       }
       return NFP_OK;
@@ -221,12 +224,13 @@ int launch_bwd_tile_t(KP g, const void* x, const void* go, const void* out, cons
 }
 
 template <int R, int M, bool POOL>
-int fwd_rm(const KP& g, const void* x, void* out, float* saved, hipStream_t st, float* part, int* nb) {
+int fwd_rm(const KP& g, const void* x, void* out, float* saved, hipStream_t st, float* part, int* nb, float* gap = nullptr,
+           float* nfpm = nullptr) {
   const bool bf = g.dtype == NFP_BF16, nhwc = !g.contig;
-  if (bf) return nhwc ? launch_fwd_tile_t<R, M, true, true, POOL>(g, x, out, saved, st, part, nb)
-                      : launch_fwd_tile_t<R, M, true, false, POOL>(g, x, out, saved, st, part, nb);
-  return nhwc ? launch_fwd_tile_t<R, M, false, true, POOL>(g, x, out, saved, st, part, nb)
-              : launch_fwd_tile_t<R, M, false, false, POOL>(g, x, out, saved, st, part, nb);
+  if (bf) return nhwc ? launch_fwd_tile_t<R, M, true, true, POOL>(g, x, out, saved, st, part, nb, gap, nfpm)
+                      : launch_fwd_tile_t<R, M, true, false, POOL>(g, x, out, saved, st, part, nb, gap, nfpm);
+  return nhwc ? launch_fwd_tile_t<R, M, false, true, POOL>(g, x, out, saved, st, part, nb, gap, nfpm)
+              : launch_fwd_tile_t<R, M, false, false, POOL>(g, x, out, saved, st, part, nb, gap, nfpm);
 }
 template <int R, int M, bool POOL>
 int bwd_rm(const KP& g, const void* x, const void* go, const void* out, const float* saved, void* gx, hipStream_t st,
@@ -240,7 +244,8 @@ int bwd_rm(const KP& g, const void* x, const void* go, const void* out, const fl
 
 }  // namespace
 
-int tile_forward(const KP& g, const void* x, void* out, float* saved, hipStream_t st, bool pool, float* part, int* nb) {
+int tile_forward(const KP& g, const void* x, void* out, float* saved, hipStream_t st, bool pool, float* part, int* nb,
+                 float* gap, float* nfpm) {
   if (!tile_ok(g, x, x)) return kNotApplicable;
   const bool cosv = hot_product(g);
   if (hot_l1(g)) {   // Norm p = 1 (the class default, nfp.py:16) and EMD (make_kp): plain maps
@@ -248,8 +253,10 @@ int tile_forward(const KP& g, const void* x, void* out, float* saved, hipStream_
     return g.R == 1 ? fwd_rm<1, kNormP1, false>(g, x, out, saved, st, part, nb) : fwd_rm<2, kNormP1, false>(g, x, out, saved, st, part, nb);
   }
   if (pool) {
-    if (cosv) return g.R == 1 ? fwd_rm<1, NFP_COSINE, true>(g, x, out, saved, st, part, nb) : fwd_rm<2, NFP_COSINE, true>(g, x, out, saved, st, part, nb);
-    return g.R == 1 ? fwd_rm<1, NFP_NORM, true>(g, x, out, saved, st, part, nb) : fwd_rm<2, NFP_NORM, true>(g, x, out, saved, st, part, nb);
+    if (cosv) return g.R == 1 ? fwd_rm<1, NFP_COSINE, true>(g, x, out, saved, st, part, nb, gap, nfpm)
+                              : fwd_rm<2, NFP_COSINE, true>(g, x, out, saved, st, part, nb, gap, nfpm);
+    return g.R == 1 ? fwd_rm<1, NFP_NORM, true>(g, x, out, saved, st, part, nb, gap, nfpm)
+                    : fwd_rm<2, NFP_NORM, true>(g, x, out, saved, st, part, nb, gap, nfpm);
   }
   if (cosv) return g.R == 1 ? fwd_rm<1, NFP_COSINE, false>(g, x, out, saved, st, part, nb) : fwd_rm<2, NFP_COSINE, false>(g, x, out, saved, st, part, nb);
   return g.R == 1 ? fwd_rm<1, NFP_NORM, false>(g, x, out, saved, st, part, nb) : fwd_rm<2, NFP_NORM, false>(g, x, out, saved, st, part, nb);
@@ -274,7 +281,7 @@ int tile_backward(const KP& g, const void* x, const void* go, const void* out, c
 
 int tile_pool_fold(const KP& g, const float* part, float* gap, float* nfpm, int nb, hipStream_t st) {
   const long long n = (long long)g.B * (g.C + g.N);
-  return launch("pool_fold", pool_fold, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, part, gap, nfpm, g.B, nb, g.C, g.N,
+  return launch("pool_fold", pool_fold<0>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, part, gap, nfpm, g.B, nb, g.C, g.N,
                 g.invP);
 }
 

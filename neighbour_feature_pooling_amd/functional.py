@@ -168,13 +168,15 @@ def _order_after_fills(device):
 
 
 def _workspace(d, device):
-    """Device pointer of the constant tables of `d` (include/nfp.h: nfp_workspace_bytes / nfp_workspace_init), or
-    None.  They depend on the geometry only, so every call with the same map size and kernel shares one buffer per
-    device.  The fill kernel is enqueued once, on the stream that first needs the tables, followed by an event
+    """Device pointer of the workspace of `d` (include/nfp.h: nfp_workspace_bytes / nfp_workspace_init: the pooled
+    kernels' arrival counters and the geometry's constant tables), or None.  It depends on the geometry only, so every call
+    with the same map size and kernel on the same stream shares one buffer.  The fill kernel is enqueued once, on the stream that first needs the tables, followed by an event
     (_order_after_fills).  Under a graph capture no table is built (the fill would only be recorded, not run, and a
     later eager call would read an unfilled buffer): that one call is planned without tables and nothing is cached —
     warm a geometry up before capturing it, as every graph user does anyway."""
-    key = (device.index, d.H, d.W, d.R, d.pad, d.stride, d.dilation, d.pad_mode, d.inner_R)
+    # (one workspace per STREAM: besides the constant tables it holds the arrival counters of the pooled kernels' row bands
+    # — include/nfp.h: one pooled launch at a time per workspace; launches on one stream are ordered)
+    key = (device.index, d.H, d.W, d.R, d.pad, d.stride, d.dilation, d.pad_mode, d.inner_R, _raw_stream(device))
     rec = _WORKSPACES.get(key)
     if rec is None:
         L = _abi.load()

@@ -168,13 +168,15 @@ def test_env_switches_take_effect_only_through_reload(lib, monkeypatch):
 
 
 def test_workspace_bytes(lib):
-    """Constant tables exist for the hot-path geometry (stride 1, pad = R, R <= 2, map <= 512 pixels) only."""
-    assert lib.nfp_workspace_bytes(ctypes.byref(_desc((64, 512, 7, 7)))) > 0
+    """Constant tables exist for the hot-path geometry (stride 1, pad = R, R <= 2, map <= 512 pixels) only; "same" maps
+    above it get the pooled tail's arrival counters alone (ABI 6)."""
+    assert lib.nfp_workspace_bytes(ctypes.byref(_desc((64, 512, 7, 7)))) > _abi.TICKET_BYTES
     assert lib.nfp_workspace_bytes(ctypes.byref(_desc((4, 192, 14, 14), R=2, pad=2, measure="norm"))) > 0
     assert lib.nfp_workspace_bytes(ctypes.byref(_desc((4, 192, 14, 14), R=2, pad=2, mode="replicate"))) > 0
     assert lib.nfp_workspace_bytes(ctypes.byref(_desc((2, 16, 9, 9), stride=2))) == 0
     assert lib.nfp_workspace_bytes(ctypes.byref(_desc((2, 16, 9, 9), pad=0))) == 0
-    assert lib.nfp_workspace_bytes(ctypes.byref(_desc((2, 16, 40, 40)))) == 0
+    assert lib.nfp_workspace_bytes(ctypes.byref(_desc((2, 16, 40, 40)))) == _abi.TICKET_BYTES
+    assert lib.nfp_workspace_bytes(ctypes.byref(_desc((2, 16, 40, 40), stride=2))) == 0
     assert lib.nfp_workspace_bytes(ctypes.byref(_desc((2, 16, 9, 9), mode="circular"))) == 0
     assert lib.nfp_workspace_bytes(ctypes.byref(_desc((1, 0, 5, 5)))) == -1
     # the same tables whatever B, C, measure: one buffer per geometry
