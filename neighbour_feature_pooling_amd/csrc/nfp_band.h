@@ -89,7 +89,13 @@ __global__ void __launch_bounds__(1024) fwd_band(const KP g, const void* __restr
   NFP_STAMP(0);
   // ---- tables first (small, shared by every workgroup: L2), then the x chunk ---------------------------------
   const uint32_t* ftt = (const uint32_t*)(ws + L.ft);
-  uint32_t fte = ftt[min(glf, N - 1) * P + pf];   // this thread's first output (n = glf, pf)
+  // this thread's outputs (n = glf, glf + Gn, ...; pf): every table entry is requested now — round 3 prefetched the first
+  // and loaded the others inside the output loop, a dependent L2 round trip per round (four at 14x14 with k = 5)
+  constexpr int kFte = (N + 3) / 4 < 6 ? (N + 3) / 4 : 6;
+  const int Gn0 = fdivi(T, Ps);
+  uint32_t fte[kFte];
+#pragma unroll
+  for (int k = 0; k < kFte; ++k) fte[k] = ftt[min(glf + k * Gn0, N - 1) * P + pf];
   uint4 fo[FoffQ<R>::v];
   {
     const uint4* fot = (const uint4*)(ws + L.foff) + (long long)p * FoffQ<R>::v;
@@ -264,8 +270,12 @@ __global__ void __launch_bounds__(1024) fwd_band(const KP g, const void* __restr
     void* ob = (char*)out + (long long)b * N * P * ES;
     const float n2p = n2[lpf];
     const float ip = VAR ? unit_or(g, inv_norm(n2p, g.inv_eps)) : inv_norm(n2p, g.inv_eps);
-    for (int n = glf; n < N; n += Gn) {
-      const uint32_t e = n == glf ? fte : ftt[n * P + pf];
+    int it = 0;
+    for (int n = glf; n < N; n += Gn, ++it) {
+      uint32_t e = fte[0];
+#pragma unroll
+      for (int k = 1; k < kFte; ++k) e = it == k ? fte[k] : e;
+      if (it >= kFte) e = ftt[n * P + pf];
       const int kind = (int)(e >> 22), pix = (int)((e >> 9) & 511u), fi = (int)((e >> 18) & 15u);
       const int q = kind == 2 ? pf : (int)(e & 511u);
       if (pix >= p0 && pix < po) {

@@ -9,7 +9,9 @@
 #include "nfp_gather.h"
 #include "nfp_mfma.h"
 #include "nfp_direct.h"
-#include "nfp_gemm2.h"
+#ifdef NFP_GEMM2_ARM   // (A/B arm, not part of the product build: the matrix-core backward with bwd_tile's table-free phase A —
+#include "nfp_gemm2.h" //  measured SLOWER at config 5, 25.5 vs 17.2 us: profiles/r04_g_…; scripts/ab_flags.py --build "-DNFP_GEMM2_ARM")
+#endif
 
 using namespace nfp;
 using namespace nfp_host;
@@ -563,8 +565,11 @@ int launch_bwd_gemm_t(KP g, const void* x, const void* go, const void* out, cons
   if (S < 1) S = 1;
   g.Cwg = ((g.C / 32 + S - 1) / S) * 32;
   S = (g.C + g.Cwg - 1) / g.Cwg;
-  // Round 4: phase A without tables, one thread per padded position (nfp_gemm2.h) — while every position has a thread and
-  // its planes fit beside the window table.  (GFC keeps the table-driven phase A: one instantiation set fewer.)
+  // Round 4 experiment (-DNFP_GEMM2_ARM builds it; NFP_GEMM2=0 switches it off at run time): phase A without tables, one
+  // thread per padded position (nfp_gemm2.h) — while every position has a thread and its planes fit beside the window
+  // table.  At config 5 a third of the workgroup's threads hold a position and walk ~500 instructions each: 13.8 us of
+  // phase A against 6.0 us for the table-driven one spread over all 1024 threads (in-kernel stamps, profiles/r04_g_…).
+#ifdef NFP_GEMM2_ARM
   if constexpr (R != 12) {
     const int npu2 = (g.H + 2 * R) * (g.W + 2 * R);
     if (g_sw.gemm2.load(std::memory_order_relaxed) && !g.gfc && npu2 <= 1024 && !(!NHWC && (g.P & 3) && S < 2)) {
@@ -594,6 +599,7 @@ int launch_bwd_gemm_t(KP g, const void* x, const void* go, const void* out, cons
       }
     }
   }
+#endif
   // NCHW rows that are not 8-byte aligned (H*W % 4 != 0) are staged and stored 2 bytes at a time: that only pays
   // while the batch is small enough for the channel split (measured: 7.2 vs 8.4 us at B = 64, 16.1 vs 14.0 at 256)
   if (!NHWC && (g.P & 3) && S < 2) return kNotApplicable;

@@ -46,7 +46,12 @@ struct Switches {
                                      // band that arrives last (nfp_common.h::pool_last_band).  Measured slower than what it
                                      // replaces (profiles/r04_e_…: 8.7 vs 6.9 us at the headline shape, 103 vs 91 us at
                                      // [256,16,112,112]): off by default
-  std::atomic<int> gemm2{1};         // A/B: the matrix-core backward with the table-free phase A (nfp_gemm2.h)
+  std::atomic<int> gemm2{1};         // A/B: the matrix-core backward with the table-free phase A (nfp_gemm2.h; -DNFP_GEMM2_ARM builds only)
+  std::atomic<int> tile_dma{-1};     // the channels-last row-band forward staged by LDS-DMA into a position-major slab
+                                     // (nfp_tile.h::fwd_tile, DMA): -1 = where it measured faster — bf16 maps of 64 channels and
+                                     // more per pixel (8 pieces per position: [256,128,28,28] 23.9 -> 18.8 us, [256,64,56,56] 44.2 ->
+                                     // 42.2) — 0 = never, 1 = wherever it applies (float32 loses: 72 -> 121 us at
+                                     // [256,16,112,112]; profiles/r04_h_…)
 };
 inline Switches g_sw;
 #ifndef NFP_MFMA_DEFAULT
@@ -63,6 +68,10 @@ inline void read_env() {
   g_sw.mfma = flag("NFP_MFMA", NFP_MFMA_DEFAULT);
   g_sw.pool_ticket = flag("NFP_POOL_TICKET", 0);
   g_sw.gemm2 = flag("NFP_GEMM2", 1);
+  {
+    const char* e = getenv("NFP_TILE_DMA");
+    g_sw.tile_dma = e ? (e[0] == '1' ? 1 : 0) : -1;
+  }
   g_sw.tile_first = flag("NFP_TILE_FIRST", 0);   // A/B: the row-band kernels of nfp_tile.h also for maps the table kernels serve
   auto num = [](const char* name) {
     const char* e = getenv(name);

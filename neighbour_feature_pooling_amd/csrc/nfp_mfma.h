@@ -47,7 +47,12 @@ __global__ void __launch_bounds__(1024) fwd_gram(const KP g, const void* __restr
   const int G = max(1, T / P), gl = fdivi(t, P), pr = t - gl * P;
   const int p = gl < G ? pr : 0;  // (surplus threads idle through the barriers below)
   const uint32_t* ftt = ws != nullptr ? (const uint32_t*)(ws + ws_layout(P, R, g.mode).ft) : nullptr;
-  const uint32_t fte = ftt != nullptr ? ftt[min(gl, N - 1) * P + p] : 0u;
+  // (round 4: ALL of the thread's table entries are requested here — up to kFte output rounds; round 3 prefetched the
+  // first and loaded the others inside the output loop, one dependent L2 round trip per round: four of them at config 5)
+  constexpr int kFte = 6;
+  uint32_t fte[kFte];
+#pragma unroll
+  for (int k = 0; k < kFte; ++k) fte[k] = ftt != nullptr ? ftt[min(gl + k * G, N - 1) * P + p] : 0u;
   if (LDSX) {
     const int cq = C >> 3;  // pieces per pixel row
     if (NCHW) {
@@ -142,10 +147,14 @@ __global__ void __launch_bounds__(1024) fwd_gram(const KP g, const void* __restr
   float* vm = n2t + 2 * P;  // [N][P] map values for the pooled means (inside the dead image)
   const float n2p = n2t[p];
   const float ip = M == NFP_COSINE ? n2t[P + p] : 0.f;
-  for (int n = gl; n < (gl < G ? N : 0); n += G) {
+  int it = 0;
+  for (int n = gl; n < (gl < G ? N : 0); n += G, ++it) {
     int q;
     if (ftt != nullptr) {
-      const uint32_t e = n == gl ? fte : ftt[n * P + p];
+      uint32_t e = fte[0];
+#pragma unroll
+      for (int k = 1; k < kFte; ++k) e = it == k ? fte[k] : e;
+      if (it >= kFte) e = ftt[n * P + p];
       q = (e >> 22) == 2u ? -1 : (int)(e & 511u);
     } else {
       int qy, qx;

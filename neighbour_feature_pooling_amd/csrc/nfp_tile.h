@@ -276,7 +276,12 @@ __device__ __forceinline__ float wave_sum(float v) {
 // GFC (nfp.py:265-276) differs from cosine in how a pair sum and the two norms combine (a reciprocal per output).
 // LDS: slab [Cc / 4][Ppb] float4 (POOL: later the band's maps [N][nbp]) | pair sums [NF][npu] | per-position factor [npu].
 // (k = 3: two workgroups of up to 1024 threads share a compute unit — 8 wavefronts per SIMD, 64 registers)
-template <int R, int M, bool BF, bool NHWC, bool POOL = false, bool GFC = false>
+// DMA (round 4; channels-last, one thread per position): the band is staged by LDS-DMA (global_load_lds_dwordx4: no
+// staging registers, no ds_write) into a POSITION-major slab — the 16-byte pieces of a position's channels side by side,
+// as they lie in memory — in its storage type: bf16 maps keep 8 channels per piece and are summed with v_dot2c_f32_bf16
+// (cosine: one instruction per channel pair and direction), half the LDS bytes of the float4 slab.  With several channel
+// chunks the NEXT chunk's DMA runs under the current chunk's sums (two slabs).  See the block in the kernel.
+template <int R, int M, bool BF, bool NHWC, bool POOL = false, bool GFC = false, bool DMA = false>
 __global__ void __launch_bounds__(1024, (R == 1 ? 8 : 4)) fwd_tile(const KP g, const TileGeo tg, const void* __restrict__ x,
                                                  void* __restrict__ out, float* __restrict__ saved,
                                                  float* __restrict__ part, float* __restrict__ gap, float* __restrict__ nfpm) {
@@ -291,29 +296,159 @@ __global__ void __launch_bounds__(1024, (R == 1 ? 8 : 4)) fwd_tile(const KP g, c
   const TilePos<R> ps(g, tg, bd, fo);
   const int G = blockDim.x, Wu = tg.Wu, Ppb = tg.Ppb, npu = tg.rows * Wu;
   const int W = g.W, P = g.P, v = ps.v;
+  static_assert(!DMA || (NHWC && !POOL), "the LDS-DMA staging: channels-last, plain maps");
   float4* slab = lds4;
   const int dump = (g.Cc >> 2) * Ppb;               // (a spare slot behind the slab)
   // (POOL: the band's map values [N][nbp], staged for the pooled sums, lie over the slab — dead by then; should they
   // need more room than the slab has, the tables start behind them)
   const int nbpA = (tg.rows - 2 * R) * g.W;
-  const int tt0 = POOL ? max(dump + 1, (N * nbpA + 3) >> 2) : dump + 1;
+  // DMA: g.Tc = log2 of the 16-byte pieces per position and chunk (PC); the slab(s) hold ((npu + 63) & ~63) * PC pieces
+  const int lpc = DMA ? g.Tc : 0, PC = 1 << lpc, npu64 = (npu + 63) & ~63;
+  const int nbuf = (DMA && g.C > g.Cc) ? 2 : 1;
+  const int tt0 = DMA ? nbuf * npu64 * PC : (POOL ? max(dump + 1, (N * nbpA + 3) >> 2) : dump + 1);
   float* Tt = (float*)(lds4 + tt0);                 // [NF][npu] pair sums per direction, then the per-position factor
   float* Fq = Tt + NF * npu;
   const Rsrc xb = make_rsrc((const char*)x + (long long)b * g.sB * ES, (long long)g.C * P * ES);
   NFP_STAMP_INIT();
   NFP_STAMP(0);
 
-  TileStage<R, BF, NHWC, false> st;
-  st.issue(g, ps, xb, G, 0, min(g.Cc, g.C) >> 2, npu);
-  __builtin_amdgcn_sched_barrier(0);
-
   float acc[NF];
 #pragma unroll
   for (int d = 0; d < NF; ++d) acc[d] = 0.f;
   float nrm = 0.f;
-  NFP_STAMP(1);
 
-  for (int c0 = 0; c0 < g.C; c0 += g.Cc) {
+  if constexpr (DMA) {
+    // ---- LDS-DMA staging + sums on the position-major slab -------------------------------------------------------------
+    // Piece (u, k) — 16 bytes: channels 4k .. (f32) / 8k .. (bf16) of position u in this chunk — lives at slab[u * PC + (k ^ f(u))], f(u) =
+    // (u >> (4 - lpc)) & (PC - 1): the XOR spreads the 16 lanes a ds_read_b128 serves per cycle (16 consecutive positions,
+    // PC pieces apart) over all 16 bank columns.  A DMA instruction writes 64 consecutive 16-byte slots (M0 base + lane * 16:
+    // the destination is not a per-lane scatter), so the swizzle goes on the SOURCE address: lane L of instruction i fills
+    // slot i * n + L of the wavefront's n * PC slots (n = the wavefront's positions: 64, fewer in a workgroup's last one),
+    // i.e. piece slot (L + i n) % PC of position (L + i n) / PC, and fetches the piece that belongs there from the position's
+    // fold source (the offset of somebody else's position comes through ds_bpermute).  Positions that read zeros (zero
+    // padding, rows past the band) write them with a plain ds_write instead: an exec-masked DMA lane leaves its slot alone.
+    // Ordering: the DMA counts in vmcnt; __syncthreads() makes every wavefront wait for its own (vmcnt(0)) and then
+    // meet the others — only then is the slab read.
+    const int lane = __lane_id(), wb = v - lane, n = min(64, npu - wb);
+    const long long xoff = (long long)b * g.sB * ES;
+    const int srcb = ps.zero ? -1 : ps.src * g.C * ES;                       // byte offset of this position's pixel, or "zeros"
+    uint4* sl = (uint4*)lds4;
+    auto dma = [&](int c0, uint4* buf) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        if (i < PC) {                                                         // (wave-uniform)
+          const int idx = lane + i * n, pl = idx >> lpc, ks = idx & (PC - 1);
+          const int sb = __builtin_amdgcn_ds_bpermute(pl << 2, srcb);
+          const int k = ks ^ (((wb + pl) >> (4 - lpc)) & (PC - 1));
+          uint4* dst = buf + (long long)wb * PC + i * n;                     // wave-uniform; the lane's slot is dst + lane
+          if (sb >= 0) {
+            const char* gp = (const char*)x + xoff + sb + c0 * ES + k * 16;
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)gp,
+                                             (void __attribute__((address_space(3)))*)dst, 16, 0, 0);
+          } else {
+            dst[lane] = make_uint4(0u, 0u, 0u, 0u);
+          }
+        }
+      }
+    };
+    // the XOR terms of this position and of its forward neighbours
+    const int fmask = PC - 1, fsh = 4 - lpc;
+    const int fv = (v >> fsh) & fmask;
+    // slot of piece k of the position under forward direction d (recomputed per use: two arrays of NF offsets cost the
+    // registers that keep two 900-thread workgroups on a compute unit)
+    auto nslot = [&](int d, int k) {
+      int dy, dx;
+      fdir<R>(d, dy, dx);
+      const int u = v + dy * Wu + dx;
+      return (u << lpc) + (k ^ ((u >> fsh) & fmask));
+    };
+    dma(0, sl);
+    NFP_STAMP(1);
+    int cur = 0;
+    for (int c0 = 0; c0 < g.C; c0 += g.Cc, cur ^= 1) {
+      __syncthreads();   // this chunk's DMA has landed; the other slab's readers (previous chunk) are done
+      if (c0 + g.Cc < g.C) dma(c0 + g.Cc, sl + (cur ^ 1) * npu64 * PC);
+      if (c0 == 0) NFP_STAMP(2);
+      if (ps.live) {
+        const uint4* bufc = sl + cur * npu64 * PC;
+        for (int k = 0; k < PC; ++k) {
+          const uint4 a = bufc[(v << lpc) + (k ^ fv)];
+          if constexpr (BF) {
+            typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+            const bf2 a0 = __builtin_bit_cast(bf2, a.x), a1 = __builtin_bit_cast(bf2, a.y), a2 = __builtin_bit_cast(bf2, a.z),
+                      a3 = __builtin_bit_cast(bf2, a.w);
+            if (M == NFP_COSINE) {
+              nrm = __builtin_amdgcn_fdot2_f32_bf16(a0, a0, nrm, false);
+              nrm = __builtin_amdgcn_fdot2_f32_bf16(a1, a1, nrm, false);
+              nrm = __builtin_amdgcn_fdot2_f32_bf16(a2, a2, nrm, false);
+              nrm = __builtin_amdgcn_fdot2_f32_bf16(a3, a3, nrm, false);
+#pragma unroll
+              for (int d = 0; d < NF; ++d) {
+                const uint4 q = bufc[nslot(d, k)];
+                float t_ = acc[d];
+                t_ = __builtin_amdgcn_fdot2_f32_bf16(a0, __builtin_bit_cast(bf2, q.x), t_, false);
+                t_ = __builtin_amdgcn_fdot2_f32_bf16(a1, __builtin_bit_cast(bf2, q.y), t_, false);
+                t_ = __builtin_amdgcn_fdot2_f32_bf16(a2, __builtin_bit_cast(bf2, q.z), t_, false);
+                t_ = __builtin_amdgcn_fdot2_f32_bf16(a3, __builtin_bit_cast(bf2, q.w), t_, false);
+                acc[d] = t_;
+              }
+            } else {
+              const uint32_t aw[4] = {a.x, a.y, a.z, a.w};
+              float af[8];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                af[2 * e] = __uint_as_float(aw[e] << 16);
+                af[2 * e + 1] = __uint_as_float(aw[e] & 0xffff0000u);
+              }
+#pragma unroll
+              for (int e = 0; e < 8; ++e) nrm = M == kNormP1 ? nrm + fabsf(af[e]) : fmaf(af[e], af[e], nrm);
+#pragma unroll
+              for (int d = 0; d < NF; ++d) {
+                const uint4 q = bufc[nslot(d, k)];
+                const uint32_t qw[4] = {q.x, q.y, q.z, q.w};
+                float t_ = acc[d];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                  const float e0 = af[2 * e] - __uint_as_float(qw[e] << 16);
+                  const float e1 = af[2 * e + 1] - __uint_as_float(qw[e] & 0xffff0000u);
+                  t_ = M == kNormP1 ? t_ + (fabsf(e0) + fabsf(e1)) : fmaf(e0, e0, fmaf(e1, e1, t_));
+                }
+                acc[d] = t_;
+              }
+            }
+          } else {
+            const float4 af = make_float4(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z), __uint_as_float(a.w));
+            if (M == kNormP1)
+              nrm += (fabsf(af.x) + fabsf(af.y)) + (fabsf(af.z) + fabsf(af.w));
+            else
+              nrm = fmaf(af.x, af.x, fmaf(af.y, af.y, fmaf(af.z, af.z, fmaf(af.w, af.w, nrm))));
+#pragma unroll
+            for (int d = 0; d < NF; ++d) {
+              const uint4 qu = bufc[nslot(d, k)];
+              const float4 q = make_float4(__uint_as_float(qu.x), __uint_as_float(qu.y), __uint_as_float(qu.z), __uint_as_float(qu.w));
+              if (M == NFP_COSINE) {
+                acc[d] = fmaf(af.x, q.x, fmaf(af.y, q.y, fmaf(af.z, q.z, fmaf(af.w, q.w, acc[d]))));
+              } else if (M == kNormP1) {
+                acc[d] += (fabsf(af.x - q.x) + fabsf(af.y - q.y)) + (fabsf(af.z - q.z) + fabsf(af.w - q.w));
+              } else {
+                const float e0 = af.x - q.x, e1 = af.y - q.y, e2 = af.z - q.z, e3 = af.w - q.w;
+                acc[d] = fmaf(e0, e0, fmaf(e1, e1, fmaf(e2, e2, fmaf(e3, e3, acc[d]))));
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+
+  TileStage<R, BF, NHWC, false> st;
+  if constexpr (!DMA) {
+    st.issue(g, ps, xb, G, 0, min(g.Cc, g.C) >> 2, npu);
+    __builtin_amdgcn_sched_barrier(0);
+    NFP_STAMP(1);
+  }
+
+  for (int c0 = 0; c0 < (DMA ? 0 : g.C); c0 += g.Cc) {
     const int ncq = min(g.Cc, g.C - c0) >> 2;
     if (c0 > 0) __syncthreads();  // previous chunk fully consumed
     st.commit(slab, g, ps, G, Ppb, ncq, dump, npu);

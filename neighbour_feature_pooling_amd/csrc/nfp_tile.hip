@@ -106,11 +106,35 @@ int launch_fwd_tile_t(KP g, const void* x, void* out, float* saved, hipStream_t 
         g.Tc = ncq >= 4 ? 2 : (ncq >= 2 ? 1 : 0);
         g.Cc = 4 << g.Tc;
       }
-      const size_t lds = std::max((size_t)(g.Cc / 4) * ppb * 16, vmb) + tail;
+      size_t lds = std::max((size_t)(g.Cc / 4) * ppb * 16, vmb) + tail;
+      // Round 4 (default: bf16 maps of >= 64 channels, where it measured faster; NFP_TILE_DMA=1 / 0 force it on / off —
+      // nfp_launch.h): channels-last, one thread per position, plain maps -> LDS-DMA into a position-major slab in the
+      // storage type (nfp_tile.h::fwd_tile, DMA): PC =
+      // 16-byte pieces per position and chunk, the largest power of two <= 8 that divides a pixel's pieces and fits (two
+      // slabs when there are several chunks).
+      bool dma = false;
+      const int dma_sw = g_sw.tile_dma.load(std::memory_order_relaxed);
+      const bool dma_auto = BF && (g.C * 2) % 128 == 0;   // (8 pieces per position and chunk: where it measured faster)
+      if ((dma_sw == 1 || (dma_sw < 0 && dma_auto)) && NHWC && !POOL && G == 1 && !g.gfc && (g.C * (BF ? 2 : 4)) % 16 == 0 &&
+          !(((uintptr_t)x) & 15) && !((g.sB * (BF ? 2 : 4)) & 15)) {
+        const int tp = g.C * (BF ? 2 : 4) / 16, npu64 = (npu + 63) & ~63;
+        for (int lpc = 3; lpc >= 0; --lpc) {
+          const int pc = 1 << lpc;
+          if (tp % pc) continue;
+          const size_t slabs = (size_t)(tp > pc ? 2 : 1) * npu64 * pc * 16;
+          const size_t slack = (size_t)(R * Wu + R + 1) * pc * 16;   // (taps past the band read whatever lies there)
+          if (slabs + tail + slack > budget) continue;
+          g.Tc = lpc;
+          g.Cc = pc * (BF ? 8 : 4);
+          lds = slabs + tail + slack;
+          dma = true;
+          break;
+        }
+      }
       nfp::TileGeo tg = {nb, rows, Wu, ppb, 1, g.H / nb, g.H % nb, (int)(lds / 4)};
       if (nb_out) *nb_out = POOL ? nb * nfp::kPoolSub : nb;   // (pooled: rows of partial sums per image)
-      snprintf(g_variant, sizeof(g_variant), "fwd_tile<R%d,%s,%s,%s%s>x%d", R, hot_name(g), BF ? "bf16" : "f32",
-               NHWC ? "nhwc" : "nchw", POOL ? ",pool" : "", nb);
+      snprintf(g_variant, sizeof(g_variant), "fwd_tile<R%d,%s,%s,%s%s%s>x%d", R, hot_name(g), BF ? "bf16" : "f32",
+               NHWC ? "nhwc" : "nchw", dma ? ",dma" : "", POOL ? ",pool" : "", nb);
       const dim3 block(G, Wu, rows);
       // (tile_ids' exact range: batches beyond kTileMaxGrid workgroups go out as several launches, images in order)
       const int es = BF ? 2 : 4, bmax = std::max(8, (tile_max_grid() / nb) & ~7);
@@ -125,10 +149,16 @@ int launch_fwd_tile_t(KP g, const void* x, void* out, float* saved, hipStream_t 
         float* gs_ = gap ? gap + (long long)b0 * g.C : nullptr;
         float* ns_ = nfpm ? nfpm + (long long)b0 * N : nullptr;
         int rc;
-        if (M == NFP_COSINE && g.gfc)
+        if (M == NFP_COSINE && g.gfc) {
           rc = launch("fwd_tile", fwd_tile<R, M, BF, NHWC, POOL, M == NFP_COSINE>, grid, block, lds, st, gs, tg, xs, os, ss, ps, gs_, ns_);
-        else
+        } else if (dma) {
+          if constexpr (NHWC && !POOL)
+            rc = launch("fwd_tile_dma", fwd_tile<R, M, BF, true, false, false, true>, grid, block, lds, st, gs, tg, xs, os, ss, ps, gs_, ns_);
+          else
+            rc = kNotApplicable;
+        } else {
           rc = launch("fwd_tile", fwd_tile<R, M, BF, NHWC, POOL, false>, grid, block, lds, st, gs, tg, xs, os, ss, ps, gs_, ns_);
+        }
         if (rc != NFP_OK) return rc;
       }
       return NFP_OK;

@@ -57,19 +57,19 @@ def test_plan_does_not_launch_or_disturb_last_variant(lib):
     (dict(shape=(64, 512, 7, 7)), "fwd_band<R1,cos,f32,nchw>x4", "bwd_fast<R1,cos,f32,nchw>"),         # headline: 4 row bands
     (dict(shape=(256, 512, 7, 7)), "fwd_band<R1,cos,f32,nchw>x1", "bwd_fast<R1,cos,f32,nchw>"),        # config 4: whole images
     (dict(shape=(256, 192, 14, 14), R=2, measure="norm", dtype=_abi.BF16), "fwd_gram<R2,l2,bf16,nchw>",
-     "bwd_gemm2<R2,l2,bf16,nchw,mfma>"),                                                                # config 5 (round 4: table-free phase A)
+     "bwd_fast<R2,l2,bf16,nchw,mfma>"),                                                                 # config 5
     (dict(shape=(256, 200, 14, 14), R=2, measure="norm", dtype=_abi.BF16), "fwd_band<R2,l2,bf16,nchw>x1",
      "bwd_fast<R2,l2,bf16,nchw>"),                                                                      # C % 16 != 0
     (dict(shape=(8, 512, 7, 7), channels_last=True), "fwd_band<R1,cos,f32,nhwc>x7", "bwd_fast<R1,cos,f32,nhwc>"),
     (dict(shape=(256, 192, 14, 14), R=2, measure="norm", dtype=_abi.BF16, channels_last=True),
-     "fwd_gram<R2,l2,bf16,nhwc>", "bwd_gemm2<R2,l2,bf16,nhwc,mfma>"),                                   # ViT tokens: matrix cores
+     "fwd_gram<R2,l2,bf16,nhwc>", "bwd_fast<R2,l2,bf16,nhwc,mfma>"),                                   # ViT tokens: matrix cores
     (dict(shape=(256, 512, 7, 7), dtype=_abi.BF16), "fwd_gram<R1,cos,bf16,nchw>", "bwd_fast<R1,cos,bf16,nchw>"),   # odd rows, no channel split
-    (dict(shape=(64, 512, 7, 7), dtype=_abi.BF16), "fwd_gram<R1,cos,bf16,nchw>", "bwd_gemm2<R1,cos,bf16,nchw,mfma>"),
-    # round 4: phase A without tables (one thread per padded position) has no entry-count limit; gfc keeps the table-driven one
+    (dict(shape=(64, 512, 7, 7), dtype=_abi.BF16), "fwd_gram<R1,cos,bf16,nchw>", "bwd_fast<R1,cos,bf16,nchw,mfma>"),
+    # the matrix-core backward's loop-free phase A: at most four gather rounds of its (up to 1024) threads
     (dict(shape=(4, 64, 16, 16), R=2, measure="norm", dtype=_abi.BF16, channels_last=True),
-     "fwd_gram<R2,l2,bf16,nhwc>", "bwd_gemm2<R2,l2,bf16,nhwc,mfma>"),
+     "fwd_gram<R2,l2,bf16,nhwc>", "bwd_fast<R2,l2,bf16,nhwc,mfma>"),                                    # 256 x 13 = 3328 entries
     (dict(shape=(4, 64, 18, 18), R=2, measure="norm", dtype=_abi.BF16, channels_last=True),
-     "fwd_gram<R2,l2,bf16,nhwc>", "bwd_gemm2<R2,l2,bf16,nhwc,mfma>"),                                   # (round 3: 4212 table entries -> vector kernel)
+     "fwd_gram<R2,l2,bf16,nhwc>", "bwd_fast<R2,l2,bf16,nhwc>"),                                         # 324 x 13 = 4212: vector kernel
     (dict(shape=(64, 512, 7, 7), measure="gfc", dtype=_abi.BF16, channels_last=True),
      "fwd_band<R1,gfc,bf16,nhwc>x4", "bwd_fast<R1,gfc,bf16,nhwc,mfma>"),
     (dict(shape=(64, 512, 7, 7), measure="norm", p=1.0), "fwd_band<R1,l1,f32,nchw>x4", "bwd_fast<R1,l1,f32,nchw>"),   # reference default p: table kernels since round 3

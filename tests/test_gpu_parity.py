@@ -842,7 +842,7 @@ def test_config5_nfp_shape_bf16_channels_last_against_oracle(kind, scale, dev, o
     bv = _abi.load().nfp_last_variant().decode()
     assert _launches() == n0 + 2
     assert fv.startswith("fwd_gram<R2,l2,bf16,nhwc"), fv
-    assert bv.startswith("bwd_gemm2<R2,l2,bf16,nhwc,mfma"), bv      # (round 4: the table-free phase A, csrc/nfp_gemm2.h)
+    assert bv.startswith("bwd_fast<R2,l2,bf16,nhwc,mfma"), bv
     assert x.grad.is_contiguous(memory_format=torch.channels_last)
     ref_out, ref_gx = _oracle_pair(oracle_lib, xh, goh, ctor)
     assert rel_err(out.detach().float().cpu().numpy(), ref_out) <= 1e-2
@@ -1156,8 +1156,8 @@ def test_distance_maps_match_the_reference_element_wise(name, dev):
 
 @pytest.mark.parametrize("shape,ctor,layout,dtype,fwd,bwd", [
     ((256, 512, 7, 7), dict(R=1, measure="cosine", padding=1), "nchw", torch.float32, "fwd_band<R1,cos,f32,nchw,pool>", "bwd_fast<R1,cos,f32,nchw,pool>"),
-    ((256, 512, 7, 7), dict(R=1, measure="cosine", padding=1), "nhwc", torch.bfloat16, "fwd_gram<R1,cos,bf16,nhwc,pool>", "bwd_gemm2<R1,cos,bf16,nhwc,mfma,pool>"),
-    ((256, 192, 14, 14), dict(R=2, measure="norm", p=2, padding=2), "nhwc", torch.bfloat16, "fwd_gram<R2,l2,bf16,nhwc,pool>", "bwd_gemm2<R2,l2,bf16,nhwc,mfma,pool>"),
+    ((256, 512, 7, 7), dict(R=1, measure="cosine", padding=1), "nhwc", torch.bfloat16, "fwd_gram<R1,cos,bf16,nhwc,pool>", "bwd_fast<R1,cos,bf16,nhwc,mfma,pool>"),
+    ((256, 192, 14, 14), dict(R=2, measure="norm", p=2, padding=2), "nhwc", torch.bfloat16, "fwd_gram<R2,l2,bf16,nhwc,pool>", "bwd_fast<R2,l2,bf16,nhwc,mfma,pool>"),
 ])
 def test_fused_pooling_tail_against_the_oracle_at_config_shapes(shape, ctor, layout, dtype, fwd, bwd, dev, oracle_lib):
     """The pooled kernels the train steps of configs[3] / configs[4] actually run (fwd_band / fwd_gram <...,pool>,
