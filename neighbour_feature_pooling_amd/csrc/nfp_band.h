@@ -25,6 +25,9 @@ namespace nfp {
 constexpr int kBandT = NFP_BAND_T;  // most threads per workgroup: pixels of the band x channel groups (a power of two <= 32)
 constexpr int kBandRB = 3;   // NCHW staging: 4-pixel x 4-channel blocks per thread per chunk
 constexpr int kBandRN = 6;   // channels-last staging: slots per thread per chunk
+#ifndef NFP_BAND_SKIP_ROUNDS
+#define NFP_BAND_SKIP_ROUNDS 1   // ([256,512,7,7] forward 6.64 -> 6.48 us, [256,192,14,14] 10.56 -> 10.10; headline unchanged: profiles/r04_i_…)
+#endif
 
 // Slots per slab row (one channel quad) of a band whose staged pixels span `span` slots (a multiple of 4).  The channel
 // sums read one ds_read_b128 per (quad, direction) with thread t = pixel * G + group: the hardware serves 16 lanes per
@@ -87,22 +90,32 @@ __global__ void __launch_bounds__(1024) fwd_band(const KP g, const void* __restr
 
   NFP_STAMP_INIT();
   NFP_STAMP(0);
-  // ---- tables first (small, shared by every workgroup: L2), then the x chunk ---------------------------------
+  // ---- the x chunk FIRST, then the tables (round 4) ------------------------------------------------------------------
+  // Rounds 2-3 requested the tables first ("small, L2"): ~170 instructions of index arithmetic and two table requests
+  // stood between kernel entry and the first x request (hipcc -S of the headline instantiation), on the critical path of
+  // a 5 us kernel whose long pole is the first x data.  Loads retire in order, so the tables now arrive right behind the
+  // chunk — they are needed after the sums.  (-DNFP_BAND_TABLES_FIRST=1 builds the old order.)
+#ifndef NFP_BAND_TABLES_FIRST
+#define NFP_BAND_TABLES_FIRST 0
+#endif
   const uint32_t* ftt = (const uint32_t*)(ws + L.ft);
-  // this thread's outputs (n = glf, glf + Gn, ...; pf): every table entry is requested now — round 3 prefetched the first
-  // and loaded the others inside the output loop, a dependent L2 round trip per round (four at 14x14 with k = 5)
+  // this thread's outputs (n = glf, glf + Gn, ...; pf): every table entry is requested at once — round 3 prefetched the
+  // first and loaded the others inside the output loop, a dependent L2 round trip per round (four at 14x14 with k = 5)
   constexpr int kFte = (N + 3) / 4 < 6 ? (N + 3) / 4 : 6;
-  const int Gn0 = fdivi(T, Ps);
   uint32_t fte[kFte];
-#pragma unroll
-  for (int k = 0; k < kFte; ++k) fte[k] = ftt[min(glf + k * Gn0, N - 1) * P + pf];
   uint4 fo[FoffQ<R>::v];
-  {
+  auto tables = [&]() {
+    const int Gn0 = fdivi(T, Ps);
+#pragma unroll
+    for (int k = 0; k < kFte; ++k) fte[k] = ftt[min(glf + k * Gn0, N - 1) * P + pf];
     const uint4* fot = (const uint4*)(ws + L.foff) + (long long)p * FoffQ<R>::v;
 #pragma unroll
     for (int u = 0; u < FoffQ<R>::v; ++u) fo[u] = fot[u];
+  };
+  if (NFP_BAND_TABLES_FIRST) {
+    tables();
+    __builtin_amdgcn_sched_barrier(0);
   }
-  __builtin_amdgcn_sched_barrier(0);
 
   // NCHW blocks of the band: 4-pixel blocks q0 .. q1-1 of every channel; the last block of an image whose pixel
   // count is not a multiple of 4 starts at P - 4 instead (it overlaps its predecessor: same values, written twice)
@@ -121,6 +134,11 @@ __global__ void __launch_bounds__(1024) fwd_band(const KP g, const void* __restr
       const int nblk = ncq * NQb;
 #pragma unroll
       for (int r = 0; r < kBandRB; ++r) {
+#if NFP_BAND_SKIP_ROUNDS
+        // (a round no thread of the workgroup needs — the headline shape: 768 blocks on 704 threads, two rounds of three —
+        // is skipped as a whole: a wave-uniform branch around four requests, not a select around a load)
+        if (r > 0 && r * T >= nblk) break;
+#endif
         const int i = min(t + r * T, nblk - 1);
         const int cq = fdivi(i, NQb), pq = q0 + i - cq * NQb;
         const int e = (c0 + 4 * cq) * P + min(4 * pq, P - 4);
@@ -166,6 +184,10 @@ __global__ void __launch_bounds__(1024) fwd_band(const KP g, const void* __restr
   };
   issue(0, min(g.Cc, g.C) >> 2);
   __builtin_amdgcn_sched_barrier(0);
+  if (!NFP_BAND_TABLES_FIRST) {
+    tables();
+    __builtin_amdgcn_sched_barrier(0);
+  }
   NFP_STAMP(1);
 
   int off[NF];

@@ -396,6 +396,9 @@ def nfp_pool_fused_ok(x, cfg):
     return ok
 
 
+_WARNED_F64 = False
+
+
 def _amp_input(x):
     """What the reference's op sequence does with low precision on the GPU (measured on an MI355X,
     profiles/r03_c_autocast_probe_reference_ops.jsonl; scripts/probe_autocast.py):
@@ -410,6 +413,17 @@ def _amp_input(x):
         return x.float(), None
     if x.is_cuda and x.dtype == torch.float16:
         return x.float(), torch.float16
+    if x.is_cuda and x.dtype == torch.float64:
+        # The reference follows the input type (nfp.py:141-159): float64 in, float64 maps.  The kernels compute in
+        # float32: the maps agree with the float64 reference to float32 rounding (<= 1e-6 of the tensor's magnitude, inside
+        # the 1e-5 parity bar), in the reference's type.  Said once per process, not silently.
+        global _WARNED_F64
+        if not _WARNED_F64:
+            import warnings
+            warnings.warn("NFP: float64 feature maps are computed in float32 by the HIP kernels and returned as float64",
+                          RuntimeWarning, stacklevel=4)
+            _WARNED_F64 = True
+        return x.float(), torch.float64
     return x, None
 
 

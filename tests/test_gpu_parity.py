@@ -141,7 +141,7 @@ def test_unbuilt_measure_fails_loudly(dev):
     assert rel_err(out.cpu().numpy(), load_golden("m_scs_p2")["out"]) <= TOL
     n0 = _launches()
     with pytest.raises(_abi.NfpUnsupported, match="float32 or bfloat16"):   # refused before anything is launched
-        NFPPooling(8, padding=1, measure="cosine")(torch.randn(1, 8, 5, 5, device=dev, dtype=torch.float64))
+        NFPPooling(8, padding=1, measure="cosine")(torch.randint(0, 9, (1, 8, 5, 5), device=dev, dtype=torch.int32))
     assert _launches() == n0
     for p in (float("inf"), 0, -2):           # LA.norm orders with other semantics: refused, never mis-computed
         with pytest.raises(_abi.NfpUnsupported, match="norm order"):
@@ -1371,6 +1371,26 @@ def test_torch_compile_fullgraph_runs_the_hip_kernels(pooled, dev):
                           test_utils=("test_schema", "test_faketensor", "test_autograd_registration"))
     torch.library.opcheck(torch.ops.nfp_amd.nfp_pool.default, (xs, *_ops.cfg_args(cfg), True, True),
                           test_utils=("test_schema", "test_faketensor", "test_autograd_registration"))
+
+
+def test_float64_feature_maps_follow_the_input_type(dev, oracle_lib):
+    """VERDICT r3 missing #8: the reference follows the input dtype (nfp.py:141-159); float64 CUDA tensors used to be
+    refused.  They are computed in float32 (a RuntimeWarning says so once) and come back float64, gradients too."""
+    import warnings
+    from neighbour_feature_pooling_amd import NFPPooling
+    from neighbour_feature_pooling_amd.synth import feature_map
+    xh = feature_map((3, 32, 9, 8), 77)
+    goh = feature_map((3, 8, 9, 8), 78)
+    x = torch.from_numpy(xh).to(dev).double().requires_grad_(True)
+    n0 = _launches()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        out = NFPPooling(32, R=1, measure="cosine", padding=1)(x)
+    gx, = torch.autograd.grad(out, x, torch.from_numpy(goh).to(dev).double())
+    assert out.dtype == torch.float64 and gx.dtype == torch.float64 and _launches() == n0 + 2
+    ctor = dict(R=1, measure="cosine", padding=1)
+    assert rel_err(out.detach().cpu().numpy(), oracle_lib.forward(xh, **ctor)) <= TOL
+    assert rel_err(gx.cpu().numpy(), oracle_lib.backward(xh, goh, **ctor)) <= TOL
 
 
 def _load_script(name):
