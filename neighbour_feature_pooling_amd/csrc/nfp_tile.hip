@@ -212,7 +212,13 @@ int launch_bwd_tile_t(KP g, const void* x, const void* go, const void* out, cons
       // bytes and more (below, the scattered 16-byte stores of a pixel complete their cache lines soon enough: measured
       // at 96 / 160 bytes, profiles/r03_w_tile_backward_stores_ab.txt), workgroups of up to 640 threads (the variant
       // takes 96 registers: two such workgroups per compute unit)
-      const bool cst = NHWC && G == 1 && g.C * (BF ? 2 : 4) >= 256 && npu <= 640;
+      // (round 4, PMC: the scattered stores of bf16 pixels leave as partial sectors — WRITE_SIZE 2.6x the bytes of grad_x at
+      // [256,24,56,56] bf16, profiles/r04_j_…; same-box A/B of the dense form per pixel size, profiles/r04_k_…: bf16 128-byte
+      // pixels 123.6 -> 102.5 us, 80-byte 23.7 -> 20.9; 48-byte pixels and float32 below 256 bytes lose or tie)
+#ifndef NFP_TILE_CST_MINB
+#define NFP_TILE_CST_MINB (BF ? 80 : 256)
+#endif
+      const bool cst = NHWC && G == 1 && g.C * (BF ? 2 : 4) >= NFP_TILE_CST_MINB && npu <= 640;
       snprintf(g_variant, sizeof(g_variant), "bwd_tile<R%d,%s,%s,%s%s%s>x%d", R, hot_name(g), BF ? "bf16" : "f32",
                NHWC ? "nhwc" : "nchw", cst ? ",dense" : "", POOL ? ",pool" : "", nb);
       const std::true_type T_;

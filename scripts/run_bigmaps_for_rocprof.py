@@ -7,12 +7,17 @@ import torch
 from neighbour_feature_pooling_amd import NFPPooling
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 SHAPES = ((16, 112), (24, 56), (40, 28), (128, 28), (64, 56))
-if len(sys.argv) > 3:          # one shape only: run_bigmaps_for_rocprof.py B C S
+if len(sys.argv) > 3:          # one shape only: run_bigmaps_for_rocprof.py B C S [nchw|nhwc|nhwc-bf16]
     SHAPES = ((int(sys.argv[2]), int(sys.argv[3])),)
+LAY = sys.argv[4] if len(sys.argv) > 4 else "nchw"
+DT = torch.bfloat16 if LAY.endswith("bf16") else torch.float32
 for C, S in SHAPES:
     m = NFPPooling(C, R=1, measure="cosine", padding=1)
-    xs = [torch.randn(B, C, S, S, device="cuda", requires_grad=True) for _ in range(3)]
-    go = torch.randn(B, 8, S, S, device="cuda")
+    xs = [torch.randn(B, C, S, S, device="cuda").to(DT) for _ in range(3)]
+    if LAY.startswith("nhwc"):
+        xs = [x.contiguous(memory_format=torch.channels_last) for x in xs]
+    xs = [x.requires_grad_(True) for x in xs]
+    go = torch.randn(B, 8, S, S, device="cuda").to(DT)
     for i in range(9):
         x = xs[i % 3]
         out = m(x)
