@@ -156,6 +156,74 @@ struct TilePos {
 // ds_bpermute.  (A workgroup's partial last wavefront keeps the one-lane-one-pixel form — a wave-uniform choice.)
 // CST (bwd_tile's variant that also STORES grad_x that way, phase B) needs every lane of every wavefront in the scheme:
 // CoopMap deals items i = lane + k * n over the n lanes a wavefront has.
+// The slab's element — four channels of one position — in the map's STORAGE type (round 4).  Rounds 2-3 kept float4 slots
+// whatever the storage: bf16 maps then took the same LDS bytes, LDS instructions and channels per chunk as float32 on half
+// the HBM bytes, and ran no faster (profiles/r03_e_…: 0.26-0.36 of their roofline against 0.46-0.64).  A bf16 slot is 8
+// bytes: half the LDS traffic, twice the channels per chunk at the same staging registers (KQ), products through
+// v_dot2c_f32_bf16.
+template <bool BF>
+struct Quad {
+  using T = float4;
+  static constexpr int KQ = kTileKQ;        // quads a thread stages per chunk
+  static __device__ __forceinline__ float4 get(const T& v) { return v; }
+  static __device__ __forceinline__ T put(const float4& v) { return v; }
+  static __device__ __forceinline__ T zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+};
+template <>
+struct Quad<true> {
+  using T = uint2;
+  static constexpr int KQ = kTileKQ;   // (8 quads per chunk at the same staging registers spilled at the 64-register bound and lost 15-30 %: profiles/r04_l_…)
+  static __device__ __forceinline__ float4 get(const T& v) {
+    return make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16),
+                       __uint_as_float(v.y & 0xffff0000u));
+  }
+  static __device__ __forceinline__ T put(const float4& v) { return make_uint2(f32_to_bf16x2(v.x, v.y), f32_to_bf16x2(v.z, v.w)); }
+  static __device__ __forceinline__ T zero() { return make_uint2(0u, 0u); }
+};
+// four consecutive channels of one pixel (channels-last), raw
+template <bool BF>
+__device__ __forceinline__ typename Quad<BF>::T load_quad(Rsrc r, int e, int srow) {
+  if constexpr (!BF) {
+    return load_px4<false>(r, e, srow);
+  } else {
+    const u32x2 u = __builtin_amdgcn_raw_buffer_load_b64(r, e * 2, srow * 2, 0);
+    return make_uint2(u.x, u.y);
+  }
+}
+template <bool BF>
+__device__ __forceinline__ void store_quad(Rsrc r, int e, int srow, const typename Quad<BF>::T& v) {
+  if constexpr (!BF) {
+    store_px4<false>(r, e, srow, v);
+  } else {
+    const u32x2 u = {v.x, v.y};
+    __builtin_amdgcn_raw_buffer_store_b64(u, r, e * 2, srow * 2, NFP_BWD_STORE_AUX);
+  }
+}
+// one position of four consecutive channel PLANES (NCHW), raw
+template <bool BF>
+__device__ __forceinline__ typename Quad<BF>::T load_quad_planes(Rsrc r, int e, int P) {
+  if constexpr (!BF) {
+    return make_float4(load_1<false>(r, e, 0), load_1<false>(r, e, P), load_1<false>(r, e, 2 * P), load_1<false>(r, e, 3 * P));
+  } else {
+    const uint32_t a = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(r, e * 2, 0, 0);
+    const uint32_t b = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(r, e * 2, P * 2, 0);
+    const uint32_t c = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(r, e * 2, 2 * P * 2, 0);
+    const uint32_t d = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(r, e * 2, 3 * P * 2, 0);
+    return make_uint2(a | (b << 16), c | (d << 16));
+  }
+}
+// sum over the quad's four channels of a[c] * q[c] (+ acc): exact products, float32 sums
+template <bool BF>
+__device__ __forceinline__ float quad_dot(const typename Quad<BF>::T& a, const typename Quad<BF>::T& q, float acc) {
+  if constexpr (!BF) {
+    return fmaf(a.x, q.x, fmaf(a.y, q.y, fmaf(a.z, q.z, fmaf(a.w, q.w, acc))));
+  } else {
+    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, a.x), __builtin_bit_cast(bf2, q.x), acc, false);
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, a.y), __builtin_bit_cast(bf2, q.y), acc, false);
+  }
+}
+
 struct CoopMap {   // the wavefront's share of a chunk, as seen by one lane
   int lq, wb, n;   // log2 Q; the wavefront's first position; its lanes
   int lane;
@@ -173,18 +241,20 @@ struct CoopMap {   // the wavefront's share of a chunk, as seen by one lane
 };
 template <int R, bool BF, bool NHWC, bool CST>
 struct TileStage {
-  float4 q[kTileKQ];
+  using QT = typename Quad<BF>::T;
+  static constexpr int KQ = Quad<BF>::KQ;
+  QT q[KQ];
   __device__ __forceinline__ void issue(const KP& g, const TilePos<R>& ps, Rsrc xb, int G, int c0, int ncq, int npu) {
     if constexpr (CST) {
       const CoopMap cm(g, ps.v, npu);
       const int eb = (ps.src * g.C) | ps.template zoff<BF>();
 #pragma unroll
-      for (int k = 0; k < kTileKQ; ++k) {
+      for (int k = 0; k < KQ; ++k) {
         int psub, cq;
         cm.item(k, psub, cq);
         const int e = __builtin_amdgcn_ds_bpermute(psub << 2, eb) + 4 * cq;
         const bool ok = k < (1 << cm.lq) && cq < ncq;
-        q[k] = load_px4<BF>(xb, ok ? e : Oob<BF>::e, c0);
+        q[k] = load_quad<BF>(xb, ok ? e : Oob<BF>::e, c0);
       }
       return;
     }
@@ -195,34 +265,35 @@ struct TileStage {
         const int cq = lane & ((1 << lq) - 1), p0 = lane >> lq, step = 64 >> lq;
         const int eb = (ps.src * g.C) | ps.template zoff<BF>();
 #pragma unroll
-        for (int k = 0; k < kTileKQ; ++k) {
+        for (int k = 0; k < KQ; ++k) {
           const int psub = p0 + k * step;
           const int e = __builtin_amdgcn_ds_bpermute(psub << 2, eb) + 4 * cq;
           const bool ok = k < (1 << lq) && cq < ncq;
-          q[k] = load_px4<BF>(xb, ok ? e : Oob<BF>::e, c0);
+          q[k] = load_quad<BF>(xb, ok ? e : Oob<BF>::e, c0);
         }
         return;
       }
     }
 #pragma unroll
-    for (int k = 0; k < kTileKQ; ++k) {
+    for (int k = 0; k < KQ; ++k) {
+      if (k > 0 && k * G >= ncq) break;             // (a round no thread of the workgroup needs: wave-uniform)
       const int cq = min(ps.gl + k * G, ncq - 1);   // (clamped: nothing conditional around a load)
       if constexpr (NHWC) {
         const int e = (ps.src * g.C + c0 + 4 * cq) | ps.template zoff<BF>();
-        q[k] = load_px4<BF>(xb, e, 0);
+        q[k] = load_quad<BF>(xb, e, 0);
       } else {
         const int e = ((c0 + 4 * cq) * g.P + ps.src) | ps.template zoff<BF>();
-        q[k] = make_float4(load_1<BF>(xb, e, 0), load_1<BF>(xb, e, g.P), load_1<BF>(xb, e, 2 * g.P), load_1<BF>(xb, e, 3 * g.P));
+        q[k] = load_quad_planes<BF>(xb, e, g.P);
       }
     }
-    }
+  }
   // (a quad past the chunk's end goes to the spare slot `dump`: an address select; a predicated LDS store costs registers)
-  __device__ __forceinline__ void commit(float4* slab, const KP& g, const TilePos<R>& ps, int G, int Ppb, int ncq, int dump,
+  __device__ __forceinline__ void commit(QT* slab, const KP& g, const TilePos<R>& ps, int G, int Ppb, int ncq, int dump,
                                          int npu) const {
     if constexpr (CST) {
       const CoopMap cm(g, ps.v, npu);
 #pragma unroll
-      for (int k = 0; k < kTileKQ; ++k) {
+      for (int k = 0; k < KQ; ++k) {
         int psub, cq;
         cm.item(k, psub, cq);
         const bool ok = k < (1 << cm.lq) && cq < ncq;
@@ -235,7 +306,7 @@ struct TileStage {
         const int lq = g.Tc, lane = __lane_id(), wb = ps.v - lane;
         const int cq = lane & ((1 << lq) - 1), p0 = lane >> lq, step = 64 >> lq;
 #pragma unroll
-        for (int k = 0; k < kTileKQ; ++k) {
+        for (int k = 0; k < KQ; ++k) {
           const int psub = p0 + k * step;
           const bool ok = k < (1 << lq) && cq < ncq;
           slab[ok ? cq * Ppb + wb + psub : dump] = q[k];
@@ -244,11 +315,11 @@ struct TileStage {
       }
     }
 #pragma unroll
-    for (int k = 0; k < kTileKQ; ++k) {
+    for (int k = 0; k < KQ; ++k) {
       const int cq = ps.gl + k * G;
       slab[cq < ncq ? cq * Ppb + ps.v : dump] = q[k];
     }
-    }
+  }
 };
 
 // Ring positions of a band, numbered compactly (the backward keeps a window row for each: 2R per padded row, and the 2R
@@ -297,7 +368,8 @@ __global__ void __launch_bounds__(1024, (R == 1 ? 8 : 4)) fwd_tile(const KP g, c
   const int G = blockDim.x, Wu = tg.Wu, Ppb = tg.Ppb, npu = tg.rows * Wu;
   const int W = g.W, P = g.P, v = ps.v;
   static_assert(!DMA || (NHWC && !POOL), "the LDS-DMA staging: channels-last, plain maps");
-  float4* slab = lds4;
+  using QT = typename Quad<BF>::T;                  // a slab slot: four channels of a position, in the storage type
+  QT* slab = (QT*)lds4;
   const int dump = (g.Cc >> 2) * Ppb;               // (a spare slot behind the slab)
   // (POOL: the band's map values [N][nbp], staged for the pooled sums, lie over the slab — dead by then; should they
   // need more room than the slab has, the tables start behind them)
@@ -305,7 +377,8 @@ __global__ void __launch_bounds__(1024, (R == 1 ? 8 : 4)) fwd_tile(const KP g, c
   // DMA: g.Tc = log2 of the 16-byte pieces per position and chunk (PC); the slab(s) hold ((npu + 63) & ~63) * PC pieces
   const int lpc = DMA ? g.Tc : 0, PC = 1 << lpc, npu64 = (npu + 63) & ~63;
   const int nbuf = (DMA && g.C > g.Cc) ? 2 : 1;
-  const int tt0 = DMA ? nbuf * npu64 * PC : (POOL ? max(dump + 1, (N * nbpA + 3) >> 2) : dump + 1);
+  const int slabq = ((dump + 1) * (int)sizeof(QT) + 15) >> 4;   // the slab and its spare slot, in 16-byte units
+  const int tt0 = DMA ? nbuf * npu64 * PC : (POOL ? max(slabq, (N * nbpA + 3) >> 2) : slabq);
   float* Tt = (float*)(lds4 + tt0);                 // [NF][npu] pair sums per direction, then the per-position factor
   float* Fq = Tt + NF * npu;
   const Rsrc xb = make_rsrc((const char*)x + (long long)b * g.sB * ES, (long long)g.C * P * ES);
@@ -470,7 +543,7 @@ __global__ void __launch_bounds__(1024, (R == 1 ? 8 : 4)) fwd_tile(const KP g, c
           float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
           for (int lp = sub * seg + lane; lp < hi; lp += 64) {
             const int yl = fdivi(lp, W), xl = lp - yl * W;
-            const float4 q = slab[cq * Ppb + (yl + R) * Wu + xl + R];
+            const float4 q = Quad<BF>::get(slab[cq * Ppb + (yl + R) * Wu + xl + R]);
             s4.x += q.x;
             s4.y += q.y;
             s4.z += q.z;
@@ -487,7 +560,7 @@ __global__ void __launch_bounds__(1024, (R == 1 ? 8 : 4)) fwd_tile(const KP g, c
           float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
           for (int lp = 0; lp < nbp; ++lp) {
             const int yl = lp / W, xl = lp - yl * W;
-            const float4 q = slab[cq * Ppb + (yl + R) * Wu + xl + R];
+            const float4 q = Quad<BF>::get(slab[cq * Ppb + (yl + R) * Wu + xl + R]);
             s4.x += q.x;
             s4.y += q.y;
             s4.z += q.z;
@@ -502,8 +575,20 @@ __global__ void __launch_bounds__(1024, (R == 1 ? 8 : 4)) fwd_tile(const KP g, c
       // (every tap at a constant offset; a tap past the padded band reads whatever lies there: such a pair is never
       // looked up)
       for (int cq = ps.gl; cq < ncq; cq += G) {
-        const float4* r0 = slab + cq * Ppb + v;
-        const float4 a = r0[0];
+        const QT* r0 = slab + cq * Ppb + v;
+        const QT araw = r0[0];
+        if constexpr (BF && M == NFP_COSINE) {   // products of two bf16 are exact in float32: v_dot2c_f32_bf16, no unpacking
+          nrm = quad_dot<BF>(araw, araw, nrm);
+#pragma unroll
+          for (int d = 0; d < NF; ++d) {
+            int dy, dx;
+            fdir<R>(d, dy, dx);
+            const QT qraw = dy == 0 ? r0[dx] : (r0 + dy * Wu - R)[dx + R];
+            acc[d] = quad_dot<BF>(araw, qraw, acc[d]);
+          }
+          continue;
+        }
+        const float4 a = Quad<BF>::get(araw);
         if (M == kNormP1)   // (Norm p = 1 — the class default, nfp.py:16,141-148 — and EMD, nfp.py:207-216: sums of |.|)
           nrm += (fabsf(a.x) + fabsf(a.y)) + (fabsf(a.z) + fabsf(a.w));
         else
@@ -512,7 +597,7 @@ __global__ void __launch_bounds__(1024, (R == 1 ? 8 : 4)) fwd_tile(const KP g, c
         for (int d = 0; d < NF; ++d) {
           int dy, dx;
           fdir<R>(d, dy, dx);
-          const float4 q = dy == 0 ? r0[dx] : (r0 + dy * Wu - R)[dx + R];   // (row base + compile-time column)
+          const float4 q = Quad<BF>::get(dy == 0 ? r0[dx] : (r0 + dy * Wu - R)[dx + R]);   // (row base + compile-time column)
           if (M == NFP_COSINE) {
             acc[d] = fmaf(a.x, q.x, fmaf(a.y, q.y, fmaf(a.z, q.z, fmaf(a.w, q.w, acc[d]))));
           } else if (M == kNormP1) {
@@ -690,7 +775,8 @@ __global__ void __launch_bounds__(1024, (R == 1 ? (CST ? 5 : 8) : 4)) bwd_tile(c
   float* ipn = (float*)lds4 + R * Wu;                       // ipn[v], margins at v < 0 and v >= npu
   float* pvb = (float*)lds4 + ((PL + 3) & ~3);
   float* PV = pvb + R * Wu;                                 // plane n at PV + n * PL
-  float4* slab = (float4*)pvb;
+  using QT = typename Quad<BF>::T;                          // a slab slot: four channels of a position, in the storage type
+  QT* slab = (QT*)pvb;
   const int dump = (g.Cc >> 2) * Ppb;                       // (a spare slot behind the slab)
   float* Wr = (float*)(slab + dump + 1) + 2 * K2;           // (2 K2 floats of slack either side: shifted reads)
   const Rsrc xb = make_rsrc((const char*)x + (long long)b * g.sB * ES, (long long)g.C * P * ES);
@@ -886,17 +972,17 @@ __global__ void __launch_bounds__(1024, (R == 1 ? (CST ? 5 : 8) : 4)) bwd_tile(c
     // (turning the results around takes 16 registers: there the next chunk is requested after the stores, not before the sums)
     if (more && !CST) st.issue(g, ps, xb, G, c0 + g.Cc, min(g.Cc, cb1 - c0 - g.Cc) >> 2, npu);
     auto one = [&](int cq) {
-      const float4* rc = slab + cq * Ppb + v - R;
+      const QT* rc = slab + cq * Ppb + v - R;
       float4 r4 = make_float4(0.f, 0.f, 0.f, 0.f);
       if (POOL && g.pool_gap) {
         const float4 gg = *(const float4*)(ggap + (long long)b * g.C + c0 + 4 * cq);
         r4 = make_float4(gg.x * g.invP, gg.y * g.invP, gg.z * g.invP, gg.w * g.invP);
       }
       if constexpr (M == kNormP1) {
-        const float4 a = (rc + 0 * Wu)[R];
+        const float4 a = Quad<BF>::get((rc + 0 * Wu)[R]);
 #pragma unroll
         for (int j = 0; j < K2; ++j) {
-          const float4 q = (rc + (j / K - R) * Wu)[j % K];
+          const float4 q = Quad<BF>::get((rc + (j / K - R) * Wu)[j % K]);
           const bool c = j == K2 / 2;
           r4.x = fmaf(w[j], sgn3(c ? a.x : a.x - q.x), r4.x);
           r4.y = fmaf(w[j], sgn3(c ? a.y : a.y - q.y), r4.y);
@@ -907,7 +993,7 @@ __global__ void __launch_bounds__(1024, (R == 1 ? (CST ? 5 : 8) : 4)) bwd_tile(c
       }
 #pragma unroll
       for (int j = 0; j < K2; ++j) {
-        const float4 q = (rc + (j / K - R) * Wu)[j % K];
+        const float4 q = Quad<BF>::get((rc + (j / K - R) * Wu)[j % K]);
         r4.x = fmaf(w[j], q.x, r4.x);
         r4.y = fmaf(w[j], q.y, r4.y);
         r4.z = fmaf(w[j], q.z, r4.z);
@@ -916,29 +1002,30 @@ __global__ void __launch_bounds__(1024, (R == 1 ? (CST ? 5 : 8) : 4)) bwd_tile(c
       return r4;
     };
     if constexpr (CST) {
-      float4 rq[kTileKQ];
+      constexpr int KQ = Quad<BF>::KQ;
+      QT rq[KQ];                                  // (results in the storage type: what the stores take)
 #pragma unroll
-      for (int k = 0; k < kTileKQ; ++k) {
-        if (k < ncq) rq[k] = one(k);             // (wave-uniform bound; non-own positions compute something nobody stores)
+      for (int k = 0; k < KQ; ++k) {
+        if (k < ncq) rq[k] = Quad<BF>::put(one(k));   // (wave-uniform bound; non-own positions compute something nobody stores)
         __builtin_amdgcn_sched_barrier(0);        // (one quad after the other: interleaved, their 36 LDS reads want 144 registers)
       }
       __syncthreads();  // chunk fully consumed: a position's slots now carry its results to the lanes that store them
 #pragma unroll
-      for (int k = 0; k < kTileKQ; ++k)
+      for (int k = 0; k < KQ; ++k)
         if (k < ncq) slab[k * Ppb + v] = rq[k];
       const CoopMap cm(g, v, npu);
       const int pc = ps.own ? p * g.C : Oob<BF>::e;
 #pragma unroll
-      for (int k = 0; k < kTileKQ; ++k) {
+      for (int k = 0; k < KQ; ++k) {
         int psub, cq;
         cm.item(k, psub, cq);
         if (k < (1 << cm.lq)) {
-          const float4 r4 = slab[min(cq, ncq - 1) * Ppb + cm.wb + psub];
+          const QT r4 = slab[min(cq, ncq - 1) * Ppb + cm.wb + psub];
           const int e = __builtin_amdgcn_ds_bpermute(psub << 2, pc) + 4 * cq;
 #ifdef NFP_TILE_NOSTORE   // (diagnostic build only: what the kernel costs without its grad_x stores)
-          if (r4.x != 12345.678f) continue;
+          if (Quad<BF>::get(r4).x != 12345.678f) continue;
 #endif
-          store_px4<BF>(gxb, cq < ncq ? e : Oob<BF>::e, c0, r4);
+          store_quad<BF>(gxb, cq < ncq ? e : Oob<BF>::e, c0, r4);
         }
       }
       if (more) st.issue(g, ps, xb, G, c0 + g.Cc, min(g.Cc, cb1 - c0 - g.Cc) >> 2, npu);

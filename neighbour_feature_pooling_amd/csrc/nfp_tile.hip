@@ -94,19 +94,20 @@ int launch_fwd_tile_t(KP g, const void* x, void* out, float* saved, hipStream_t 
       const int ppb = nfp::band_row_slots((npu + 3) & ~3, lg);
       const size_t tail = 16 + (size_t)(NF + 1) * npu * 4;                      // spare slot, pair sums, factors
       const size_t vmb = POOL ? (((size_t)N * nbp + 3) / 4) * 16 : 0;            // pooled: the band's maps, over the slab
-      if (tail + std::max((size_t)ppb * 16, vmb) > budget) continue;
-      int ncq = (int)((budget - tail) / ((size_t)ppb * 16));
-      ncq = std::min(ncq, std::min(nfp::kTileKQ * G, g.C / 4));
+      constexpr size_t SB = BF ? 8 : 16;   // bytes of a slab slot (four channels of a position in the storage type: nfp_tile.h::Quad)
+      if (tail + std::max((size_t)ppb * SB, vmb) > budget) continue;
+      int ncq = (int)((budget - tail) / ((size_t)ppb * SB));
+      ncq = std::min(ncq, std::min(nfp::Quad<BF>::KQ * G, g.C / 4));
       if (ncq < 1) continue;
       const int total = g.C / 4, nch = ceil_div(total, ncq);
       g.Cc = 4 * ceil_div(total, nch);
       g.G = G;
       g.Tc = -1;
-      if (NHWC && G == 1) {   // wavefront-shared staging: chunks of 1, 2 or 4 quads (nfp_tile.h::TileStage)
-        g.Tc = ncq >= 4 ? 2 : (ncq >= 2 ? 1 : 0);
+      if (NHWC && G == 1) {   // wavefront-shared staging: chunks of 1, 2, 4 (bf16: 8) quads (nfp_tile.h::TileStage)
+        g.Tc = (BF && ncq >= 8) ? 3 : (ncq >= 4 ? 2 : (ncq >= 2 ? 1 : 0));
         g.Cc = 4 << g.Tc;
       }
-      size_t lds = std::max((size_t)(g.Cc / 4) * ppb * 16, vmb) + tail;
+      size_t lds = std::max((size_t)(g.Cc / 4) * ppb * SB, vmb) + tail;
       // Round 4 (default: bf16 maps of >= 64 channels, where it measured faster; NFP_TILE_DMA=1 / 0 force it on / off —
       // nfp_launch.h): channels-last, one thread per position, plain maps -> LDS-DMA into a position-major slab in the
       // storage type (nfp_tile.h::fwd_tile, DMA): PC =
@@ -193,19 +194,20 @@ int launch_bwd_tile_t(KP g, const void* x, const void* go, const void* out, cons
       S = ceil_div(g.C, g.Cwg);
       const int lg = tile_groups(g, nb * S, npu, kCap, g.Cwg / 4), G = 1 << lg;
       const int ppb = nfp::band_row_slots((npu + 3) & ~3, lg);
-      if (fixed + wr + (size_t)ppb * 16 > budget) continue;
-      int ncq = (int)((budget - fixed - wr) / ((size_t)ppb * 16));
-      ncq = std::min(ncq, std::min(nfp::kTileKQ * G, g.Cwg / 4));
+      constexpr size_t SB = BF ? 8 : 16;   // bytes of a slab slot (nfp_tile.h::Quad)
+      if (fixed + wr + (size_t)ppb * SB > budget) continue;
+      int ncq = (int)((budget - fixed - wr) / ((size_t)ppb * SB));
+      ncq = std::min(ncq, std::min(nfp::Quad<BF>::KQ * G, g.Cwg / 4));
       if (ncq < 1) continue;
       const int total = g.Cwg / 4, nch = ceil_div(total, ncq);
       g.Cc = 4 * ceil_div(total, nch);
       g.G = G;
       g.Tc = -1;
       if (NHWC && G == 1) {
-        g.Tc = ncq >= 4 ? 2 : (ncq >= 2 ? 1 : 0);
+        g.Tc = (BF && ncq >= 8) ? 3 : (ncq >= 4 ? 2 : (ncq >= 2 ? 1 : 0));
         g.Cc = 4 << g.Tc;
       }
-      const size_t lds = fixed + std::max(pv, (size_t)(g.Cc / 4) * ppb * 16 + wr);
+      const size_t lds = fixed + std::max(pv, (size_t)(g.Cc / 4) * ppb * SB + wr);
       nfp::TileGeo tg = {nb, rows, Wu, ppb, S, g.H / nb, g.H % nb, (int)(lds / 4)};
       const dim3 block(G, Wu, rows);
       // dense grad_x stores through LDS (nfp_tile.h, phase B): channels-last with one thread per position, pixels of 256
