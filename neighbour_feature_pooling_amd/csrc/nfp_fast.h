@@ -114,6 +114,15 @@ struct Staged<true> {
   float4 v[kRN];
 };
 
+// Slab row (one channel quad) stride in slots.  NCHW: P rounded up to 4.  Channels-last (round 4): the backward's lanes run
+// along the channel GROUPS of a pixel (below), so 16 lanes of a ds_read / ds_write_b128 are 16 consecutive quads of one
+// pixel, a row stride apart: the stride is made odd, which spreads them over the 16 bank columns.
+#ifndef NFP_BWD_NHWC_LANES
+#define NFP_BWD_NHWC_LANES 1   // (0 builds round 3's thread map: A/B)
+#endif
+__host__ __device__ inline int bwd_row_slots(int P, bool nhwc) {
+  return (nhwc && NFP_BWD_NHWC_LANES) ? (((P + 3) & ~3) | 1) : ((P + 3) & ~3);
+}
 // channels-last: slot (cq, p) is 4 contiguous channels; thread (p, gl) takes cq = gl, gl+G, ...
 template <bool BF>
 __device__ __forceinline__ void stage_load(Staged<true>& s, Rsrc x, const KP& g, int c0, int ncq, int p, int gl,
@@ -131,7 +140,7 @@ __device__ __forceinline__ void stage_store(const Staged<true>& s, float4* slab,
 #pragma unroll
   for (int k = 0; k < kRN; ++k) {
     const int cq = gl + k * g.G;
-    if (active && cq < ncq) slab[cq * ((g.P + 3) & ~3) + swz(p)] = s.v[k];
+    if (active && cq < ncq) slab[cq * bwd_row_slots(g.P, true) + swz(p)] = s.v[k];
   }
 }
 
@@ -503,8 +512,23 @@ __global__ void __launch_bounds__(GEMM ? 1024 : kBwdThreads) bwd_fast(const KP g
     if (g.pool_gap && t < ncw) ggv0 = ggap[(long long)b * g.C + cb0 + t];
     if (g.pool_gap && t + T < ncw) ggv1 = ggap[(long long)b * g.C + cb0 + t + T];
   }
-  const int gl = fast_div(t, g.invP), p = t - gl * P;
-  const bool active = gl < g.G;
+  // Thread map.  NCHW: t = gl * P + p — lanes along the pixels of a channel row (coalesced 4-byte stores).  Channels-last
+  // (round 4): t = p * G + gl — lanes along the channel groups of a pixel, so that G adjacent lanes read and write 16 G
+  // contiguous bytes; with lanes along the pixels every load / store instruction touched 64 cache lines for 1 KB, and the
+  // eight quads of a 128-byte line were written by eight different wavefronts (the backward ran 20-40 % behind NCHW on the
+  // same bytes: [4096,512,7,7] 231 vs 163 us, profiles/r04_a_…).
+  int gl, p;
+  bool active;
+  if constexpr (NHWC && !GEMM && NFP_BWD_NHWC_LANES) {
+    const int pp = fdivi(t, g.G);
+    gl = t - pp * g.G;
+    active = pp < P;
+    p = min(pp, P - 1);
+  } else {
+    gl = fast_div(t, g.invP);
+    p = t - gl * P;
+    active = gl < g.G;
+  }
   constexpr int ES = BF ? 2 : 4;
   const Rsrc xb = make_rsrc((const char*)x + (long long)b * g.sB * ES, (long long)g.C * P * ES);  // wave-uniform
   const Rsrc gxb = make_rsrc((char*)gx + (long long)b * g.gB * ES, (long long)g.C * P * ES);
@@ -842,7 +866,7 @@ __global__ void __launch_bounds__(GEMM ? 1024 : kBwdThreads) bwd_fast(const KP g
   // B: one pass over the channel block; results leave straight from registers — 4 dwords per slot for NCHW, one
   // 16-byte store for channels-last (store policy: NFP_BWD_STORE_AUX above; an LDS-transposed 16-byte NCHW epilogue
   // was 1.6 us slower).
-  const int Pp = (P + 3) & ~3, sp = swz(p);
+  const int Pp = bwd_row_slots(P, NHWC), sp = swz(p);
   for (int c0 = cb0; c0 < cb1; c0 += g.Cc) {
     const int ncq = min(g.Cc, cb1 - c0) >> 2;
     if (c0 > cb0) __syncthreads();  // previous chunk fully consumed

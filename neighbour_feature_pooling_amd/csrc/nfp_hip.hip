@@ -367,7 +367,7 @@ bool fast_ok(const KP& g, const void* x, const void* gx) {
 
 // channels per LDS chunk: bounded by the slab budget and by what one staging round-set can carry
 int chunk_channels(const KP& g, int total, int T, int G, bool nhwc, int budget) {
-  int ncq = budget / (((g.P + 3) & ~3) * 16);
+  int ncq = budget / (nfp::bwd_row_slots(g.P, nhwc) * 16);
   if (nhwc) {
     if (ncq > kRN * G) ncq = kRN * G;
   } else {  // ceil(P/4) blocks per channel row, the last one overlapping (nfp_fast.h: StagedOvl)
@@ -513,7 +513,7 @@ int launch_bwd_fast_t(KP g, const void* x, const void* go, const void* out, cons
   T = ((g.P * g.G + 63) / 64) * 64;
   g.Cc = chunk_channels(g, g.Cwg, T, g.G, NHWC, bbudget);
   const size_t fixed = bwd_fixed_bytes(g, K2), pairs = bwd_pair_bytes(g, M, N);
-  const size_t slab = (size_t)(g.Cc / 4) * ((g.P + 3) & ~3) * 16;
+  const size_t slab = (size_t)(g.Cc / 4) * nfp::bwd_row_slots(g.P, NHWC) * 16;
   g.early = fixed + pairs + slab <= kEarlyBudget ? 1 : 0;
   const size_t lds = g.early ? fixed + pairs + slab : fixed + std::max(pairs, slab);
   if (lds > (size_t)kLdsMax) return kNotApplicable;  // tables + slab do not fit: the generic kernels serve it

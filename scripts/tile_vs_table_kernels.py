@@ -25,7 +25,11 @@ def warm(fn, ms=30.0):
 cases = [(64, 512, 7, 1, "cosine", "nchw", "f32"), (256, 512, 7, 1, "cosine", "nchw", "f32"), (4096, 512, 7, 1, "cosine", "nchw", "f32"),
          (256, 960, 7, 1, "cosine", "nchw", "f32"), (256, 112, 14, 1, "cosine", "nchw", "f32"), (256, 256, 14, 1, "cosine", "nchw", "f32"),
          (256, 192, 14, 2, "norm", "nchw", "f32"), (256, 192, 14, 2, "norm", "nhwc", "bf16"), (256, 256, 14, 1, "cosine", "nhwc", "bf16"),
-         (64, 512, 7, 2, "cosine", "nchw", "f32")]
+         (64, 512, 7, 2, "cosine", "nchw", "f32"),
+         # round 4: where do the row-band kernels (bf16 slots since round 4; dense channels-last stores) beat the tables?
+         (256, 192, 14, 2, "norm", "nhwc", "f32"), (256, 192, 14, 2, "cosine", "nchw", "f32"), (256, 256, 14, 2, "norm", "nchw", "f32"),
+         (256, 112, 14, 2, "cosine", "nchw", "f32"), (256, 192, 14, 1, "cosine", "nhwc", "f32"), (256, 256, 14, 1, "cosine", "nhwc", "f32"),
+         (256, 200, 14, 2, "norm", "nhwc", "bf16"), (256, 512, 7, 1, "cosine", "nhwc", "f32"), (256, 960, 7, 1, "cosine", "nhwc", "f32")]
 for B, C, S, R, meas, lay, dt in cases:
     ctor = dict(R=R, measure=meas, padding=R)
     if meas == "norm":
