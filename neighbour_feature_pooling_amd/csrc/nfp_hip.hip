@@ -813,6 +813,12 @@ int backward_impl(const nfp_desc* d, const void* x, const void* grad_out, const 
   }
   if (g_sw.tile_first.load(std::memory_order_relaxed))
     if (int rc = tile_backward(g, x, grad_out, out, saved, grad_x, st, false, nullptr, nullptr); rc != kNotApplicable) return rc;
+  // k = 5, float32 NCHW, maps of 14 x 14 and more: the row-band backward (window weights in registers, no 13-entry-per-pixel
+  // gather phase) beats the table kernel — [256,192,14,14] L2 40.9 -> 35.7 us, cosine 41.1 -> 37.1, [256,256,14,14] 50.5 ->
+  // 44.1 (profiles/r04_n_…; the FORWARD stays on the tables: 19 vs 28 us; channels-last and bf16 stay too).  Same saved
+  // state (the map and |x| per pixel), so the two mix.
+  if (g.R == 2 && g.rs != 12 && g.dtype == NFP_F32 && g.contig && g.P >= 196 && hot_measure(g))
+    if (int rc = tile_backward(g, x, grad_out, out, saved, grad_x, st, false, nullptr, nullptr); rc != kNotApplicable) return rc;
   if (g.ws != nullptr && fast_ok(g, x, grad_x) && hot_l1(g)) {
     const int rc = g.R == 1 ? launch_bwd_vec<1, kNormP1>(g, x, grad_out, out, saved, grad_x, st)
                             : launch_bwd_vec<2, kNormP1>(g, x, grad_out, out, saved, grad_x, st);

@@ -94,6 +94,10 @@ def test_plan_does_not_launch_or_disturb_last_variant(lib):
     (dict(shape=(2, 8, 100, 140), measure="emd"), "fwd_tile<R1,l1,f32,nchw>x50", "bwd_tile<R1,l1,f32,nchw>x50"),
     (dict(shape=(256, 64, 56, 56), measure="norm", p=1.0), "fwd_tile<R1,l1,f32,nchw>x10", "bwd_tile<R1,l1,f32,nchw>x10"),
     (dict(shape=(64, 512, 7, 7), measure="emd"), "fwd_band<R1,l1,f32,nchw>x4", "bwd_fast<R1,l1,f32,nchw>"),
+    # round 4: k = 5 float32 NCHW on 14 x 14 and larger: forward on the tables, BACKWARD on the row-band kernel (measured faster)
+    (dict(shape=(256, 192, 14, 14), R=2, measure="norm"), "fwd_band<R2,l2,f32,nchw>x1", "bwd_tile<R2,l2,f32,nchw>x2"),
+    (dict(shape=(256, 192, 14, 14), R=2, measure="norm", channels_last=True), "fwd_band<R2,l2,f32,nhwc>x1", "bwd_fast<R2,l2,f32,nhwc>"),
+    (dict(shape=(64, 512, 7, 7), R=2, measure="cosine"), "fwd_band<R2,cos,f32,nchw>x4", "bwd_fast<R2,cos,f32,nchw>"),
     (dict(shape=(2, 16, 64, 64), mode="circular"), "fwd_pairs", "bwd_direct"),                        # wraps: no bands
 ])
 def test_which_kernel_serves_which_call(lib, d_kw, fwd, bwd):
