@@ -336,7 +336,7 @@ __global__ void __launch_bounds__(1024) fwd_band(const KP g, const void* __restr
     if (M == NFP_COSINE && !g.unit && saved != nullptr && glf == 0 && pf < po) saved[(long long)b * P + pf] = __builtin_amdgcn_sqrtf(n2p);
   }
   if constexpr (POOL) {
-    __syncthreads();
+    lds_barrier();   // (not __syncthreads(): the map stores just issued drain under the sums — nfp_common.h)
     // wave w reduces map n = w, w + nwaves, ...: lane-strided partial sums over the outputs THIS band wrote, then a
     // fixed shuffle tree
     const float* vm = Tt + NV;

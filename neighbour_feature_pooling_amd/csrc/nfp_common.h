@@ -231,6 +231,13 @@ __device__ __forceinline__ int fdivi(int i, int d) {
   return (int)(((float)i + 0.5f) * __builtin_amdgcn_rcpf((float)d));
 }
 
+// A workgroup barrier that orders LDS traffic ONLY.  __syncthreads() also fences global memory: hipcc puts s_waitcnt
+// vmcnt(0) in front of the barrier, and on gfx9 vmcnt counts STORES — a barrier right behind a kernel's output stores stalls
+// every wavefront until its stores are acknowledged by memory (1-2 us).  The fused pooling tail sums the map values it
+// has just stored (from an LDS copy): with this barrier its stores drain under the sums ([256,16,112,112] pooled forward
+// headline 6.91 -> 6.55 us; the row-band kernels do not change: profiles/r04_o_…).  Use only where the code behind the barrier reads nothing the stores wrote.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // sum over the G adjacent lanes of a group (G a power of two <= 32); valid in the group's LAST lane (in every lane of
 // the group for G <= 16).  DPP lane exchanges: no LDS round trip, a fixed order.
 #define NFP_DPP_ADD(v, ctrl, rows) \

@@ -180,7 +180,7 @@ __global__ void __launch_bounds__(1024) fwd_gram(const KP g, const void* __restr
   }
   if (M == NFP_COSINE && saved != nullptr && gl == 0) saved[(long long)b * P + p] = __builtin_amdgcn_sqrtf(n2p);
   if (nfpm != nullptr) {
-    __syncthreads();
+    lds_barrier();   // (the map stores just issued drain under the sums — nfp_common.h)
     // wave w reduces map n = w, w + nwaves, ...: lane-strided partial sums, then a fixed shuffle tree
     for (int n = wave; n < N; n += T >> 6) {
       float sacc = 0.f;

@@ -679,7 +679,7 @@ __global__ void __launch_bounds__(1024, (R == 1 ? 8 : 4)) fwd_tile(const KP g, c
   }
   if constexpr (POOL) {
     // this band's share of sum over pixels of out[n]: (map, segment) items over the full wavefronts, a fixed order
-    __syncthreads();
+    lds_barrier();   // (not __syncthreads(): the map stores just issued drain under the sums — nfp_common.h)
     const int t = ps.gl + G * v, lane = t & 63, wv = t >> 6, nw = (G * npu) >> 6;
     const int nbp = (bd.y1 - bd.y0) * W, seg = (nbp + kPoolSub - 1) / kPoolSub;
     const Rsrc pb = pool_rsrc(part + ((long long)b * tg.nb + band) * kPoolSub * (g.C + N), (long long)kPoolSub * (g.C + N));
