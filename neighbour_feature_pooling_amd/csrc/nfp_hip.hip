@@ -501,7 +501,11 @@ int launch_bwd_fast_t(KP g, const void* x, const void* go, const void* out, cons
 #ifndef NFP_BWD_SAT_SLAB
 #define NFP_BWD_SAT_SLAB 2
 #endif
-  const bool satb = K2 <= 9 && (long long)g.B * S >= 1024 && g.P <= NFP_BWD_SAT_T && NFP_BWD_SAT_T < kBwdThreads;
+  // (channels-last, lanes along a pixel's channel groups since round 4: a quarter-size workgroup has G = 5 groups at 7x7 —
+  // 80-byte runs of a 2 KB pixel; with 512 threads G = 10: [4096,512,7,7] 209 -> 147 us, [1024,512,7,7] 45 -> 38; narrow
+  // pixels keep the quarter size: [4096,64,7,7] 27 vs 32 us — profiles/r04_p_…)
+  const bool satb = K2 <= 9 && (long long)g.B * S >= 1024 && g.P <= NFP_BWD_SAT_T && NFP_BWD_SAT_T < kBwdThreads &&
+                    !(NHWC && g.C > 128);
   g.G = (satb ? NFP_BWD_SAT_T : kBwdThreads) / g.P;
   if (g.G < 1) g.G = 1;
   if (g.G > g.Cwg / 4) g.G = g.Cwg / 4;
