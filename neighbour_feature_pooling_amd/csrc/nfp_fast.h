@@ -195,7 +195,21 @@ __device__ __forceinline__ float inv_norm(float n2, float inv_eps) {
 // and the same two LDS images serve both orientations: A = Xt, B = Wd gives D[channel][pixel] (lanes along
 // pixels: coalesced NCHW stores), A = Wd, B = Xt gives D[pixel][channel] (channels-last stores).
 // Row tiles are processed a few at a time (Wd of all of them does not fit next to Xt at config 5's shape: g.Tc).
-__device__ __forceinline__ int odd_up(int v) { return v | 1; }
+__host__ __device__ __forceinline__ int odd_up(int v) { return v | 1; }
+// A row tile's window of summed pixels starts at ts = (32 it - band) rounded DOWN to a whole 16-byte piece of Xt (8 pixels:
+// lane half h reads piece 2 s + h of step s), never below 0; 32 it is a multiple of 8, so the rounding slack is the same for
+// every tile: (-band) mod 8.  KW: 16-pixel steps that cover 32 rows + the band on both sides + that slack.  (Round 4: the
+// start was rounded to a whole step before — 7 steps instead of 6 at config 5's 14 x 14, k = 5, and a Wd of 15 pieces per
+// row instead of 13: three row tiles per round next to Xt instead of four.)
+#ifndef NFP_GEMM_ALIGN8
+#define NFP_GEMM_ALIGN8 1   // 0 = round 3's whole-step alignment (A/B)
+#endif
+__host__ __device__ __forceinline__ int gemm_kw(int band) {
+  return NFP_GEMM_ALIGN8 ? (32 + 2 * band + ((-band) & 7) + 15) >> 4 : (32 + 2 * band + 30) >> 4;
+}
+__host__ __device__ __forceinline__ int gemm_ts(int it, int band) {
+  return (32 * it - band) < 0 ? 0 : ((32 * it - band) & (NFP_GEMM_ALIGN8 ? ~7 : ~15));
+}
 
 // ---- Xt: 8 consecutive pixels of one channel per 16-byte piece; pixels past P are zero --------------------------
 // The image block arrives 2-3 us after it is asked for, whatever the cache level, so each thread asks for its FIRST
@@ -252,6 +266,34 @@ __device__ __forceinline__ void gemm_x_issue(GemmX<NHWC>& s, const KP& g, const 
 #pragma unroll
     for (int u = 0; u < 4; ++u)
       if ((u == 0 ? 0 : u - 1) == part) gemm_fetch_row(s.v[u], g, xb, cb0, pg, min(t + u * T, ncw * pg - 1));
+  }
+}
+// Second form: the same request, ordered by the chunk a piece belongs to — chunk 0 in front of the first gather round, chunk 1
+// in front of the second, the rest in front of the third: the first chunk's tiles start as soon as the weights are complete.
+template <bool NHWC>
+__device__ __forceinline__ void gemm_x_issue3(GemmX<NHWC>& s, const KP& g, const uint16_t* xb, int cb0, int ncw, int cx, int t, int T,
+                                              int round) {
+  const int P = g.P, pg = (P + 7) >> 3;
+  if constexpr (NHWC) {
+    const int co4 = ncw >> 5, nblk = co4 * ((pg + 15) >> 4);
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    if (wave < nblk) {
+      const int bk = wave - fdivi(wave, co4) * co4, c = fdivi(32 * bk, cx);
+      if (min(c, 2) == round) {
+        int k, gq;
+        gemm_block_of(wave, co4, t & 63, k, gq);
+        if (gq < pg) {
+#pragma unroll
+          for (int u = 0; u < 8; ++u) s.v[u] = *(const uint4*)(xb + (long long)min(8 * gq + u, P - 1) * g.C + cb0 + 8 * k);
+        }
+      }
+    }
+  } else if ((P & 3) == 0) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = min(t + u * T, ncw * pg - 1), c = fdivi(fdivi(i, pg), cx);
+      if (min(c, 2) == round) gemm_fetch_row(s.v[u], g, xb, cb0, pg, i);
+    }
   }
 }
 template <bool NHWC>
@@ -323,6 +365,86 @@ __device__ __forceinline__ void gemm_stage_x(const KP& g, uint4* Xt, const uint1
   }
 }
 
+// One 32 x 32 output tile on one wavefront: row tile `it` (its densified weights Wrow: hi image, lo image 32 rows further),
+// channel tile ctx of the Xt image at hand = channel tile ct of the workgroup's block.
+template <bool NHWC>
+__device__ __forceinline__ void gemm_out_tile(const KP& g, const uint4* Wrow, const uint4* Xt, int it, int ctx, int ct, int band,
+                                              int KW, int xq, int wq, uint16_t* gxb, int cb0, int lane, const float* gg) {
+  const int P = g.P, C = g.C, r = lane & 31, h = lane >> 5;
+  const int ts = gemm_ts(it, band);
+  const int ks = min(KW, (P - ts + 15) >> 4);   // steps whose pixels exist
+  const uint4* Wh = Wrow + (long long)r * wq + h;
+  const uint4* Wl = Wh + 32 * wq;
+  const uint4* Xr = Xt + (long long)(32 * ctx + r) * xq + (ts >> 3) + h;
+  // Orientation: the accumulator holds 4 CONSECUTIVE rows per register group, so the output index that is
+  // contiguous in memory goes on the rows and leaves as one 8-byte store per group: channels for
+  // channels-last (A = Xt), pixels for NCHW (A = Wd; needs P % 4 == 0 for the alignment, otherwise pixels
+  // stay on the lanes and leave as 2-byte stores).
+  const bool rows_are_channels = NHWC || (P & 3) != 0;
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {  // element e of lane (r, h) is D[row (e & 3) + 8 (e >> 2) + 4 h][column r]
+    const int ch = 32 * ct + (rows_are_channels ? (e & 3) + 8 * (e >> 2) + 4 * h : r);
+    acc[e] = gg != nullptr ? gg[ch] : 0.f;
+  }
+  for (int s = 0; s < ks; ++s) {
+    const bf16x8 wh = __builtin_bit_cast(bf16x8, Wh[2 * s]), wl = __builtin_bit_cast(bf16x8, Wl[2 * s]);
+    const bf16x8 xv = __builtin_bit_cast(bf16x8, Xr[2 * s]);
+    if (rows_are_channels) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xv, wl, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xv, wh, acc, 0, 0, 0);
+    } else {
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, xv, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xv, acc, 0, 0, 0);
+    }
+  }
+  if (NHWC) {            // D[row = channel][col = pixel]: 4 consecutive channels of pixel r per register group
+    // Lane (r, h) holds channels 4h + {0-3, 8-11, 16-19, 24-27} of pixel r: four 8-byte pieces, and four store
+    // instructions of 64 scattered pieces each were the longest part of a round (the texture path takes an address
+    // per lane: 12 tiles x 4 x 64 per round).  v_permlane32_swap trades the packed groups between lanes r and
+    // r + 32, so that each holds 8 consecutive channels twice: two 16-byte stores.
+    const int pp = 32 * it + r;
+    uint32_t pk[8];
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+      pk[2 * gq] = f32_to_bf16x2(acc[4 * gq], acc[4 * gq + 1]);
+      pk[2 * gq + 1] = f32_to_bf16x2(acc[4 * gq + 2], acc[4 * gq + 3]);
+    }
+#pragma unroll
+    for (int gp = 0; gp < 4; gp += 2) {   // (groups gp, gp + 1): the upper lanes' gp <-> the lower lanes' gp + 1
+#pragma unroll
+      for (int d = 0; d < 2; ++d) {
+        const auto sw = __builtin_amdgcn_permlane32_swap(pk[2 * gp + d], pk[2 * gp + 2 + d], false, false);
+        pk[2 * gp + d] = sw[0];
+        pk[2 * gp + 2 + d] = sw[1];
+      }
+    }
+    if (pp < P) {
+      uint16_t* dst = gxb + (long long)pp * C + cb0 + 32 * ct + 8 * h;
+      *(uint4*)dst = make_uint4(pk[0], pk[1], pk[2], pk[3]);          // channels 8h .. 8h + 7
+      *(uint4*)(dst + 16) = make_uint4(pk[4], pk[5], pk[6], pk[7]);   // channels 16 + 8h .. 16 + 8h + 7
+    }
+  } else if ((P & 3) == 0) {  // D[row = pixel][col = channel]: 4 consecutive pixels of channel r per group
+    uint16_t* dst = gxb + (long long)(cb0 + 32 * ct + r) * P + 32 * it + 4 * h;
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+      if (32 * it + 8 * gq + 4 * h < P) {  // (P % 4 == 0: a whole group or none)
+        uint2 w;
+        w.x = f32_to_bf16x2(acc[4 * gq], acc[4 * gq + 1]);
+        w.y = f32_to_bf16x2(acc[4 * gq + 2], acc[4 * gq + 3]);
+        *(uint2*)(dst + 8 * gq) = w;
+      }
+    }
+  } else {               // D[row = channel][col = pixel], NCHW with odd rows: lanes along pixels, 2-byte stores
+    const int pp = 32 * it + r;
+    if (pp < P) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e)
+        gxb[(long long)(cb0 + 32 * ct + (e & 3) + 8 * (e >> 2) + 4 * h) * P + pp] = f32_to_bf16(acc[e]);
+    }
+  }
+}
+
 // gg: (fused pooling tail) this workgroup's channels of grad(GAP(x)) / P, staged in LDS by bwd_fast, or null: every
 // grad_x[c][p] also gets gg[c - cb0].  (Read from global memory in the tile loop they cost 4 of 22 us at config 5.)
 // Xt, Wd: the two operand images in LDS (placed by bwd_fast); pre: the share of x requested at kernel entry.
@@ -331,12 +453,12 @@ __device__ __forceinline__ void bwd_gemm_phase(const KP& g, const float* Wt, uin
                                                const uint16_t* xb, uint16_t* gxb, int cb0, int cb1, int t, int T,
                                                const float* gg = nullptr) {
   constexpr int K = Win<R>::K, K2 = Win<R>::K2;
-  const int P = g.P, C = g.C, band = R * g.W + R, nt = (P + 31) >> 5;
-  const int KW = (32 + 2 * band + 15 + 15) >> 4;            // k-steps that cover a row tile's window after aligning its start
+  const int P = g.P, band = R * g.W + R, nt = (P + 31) >> 5;
+  const int KW = gemm_kw(band);                             // k-steps that cover a row tile's window after aligning its start
   const int xq = gemm_xq(P);                                // 16-byte pieces per Xt row
   const int wq = odd_up(2 * KW + 1);                        // pieces per Wd row
   const int ncw = cb1 - cb0;                                // channels of this workgroup (multiple of 32)
-  const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), nw = T >> 6, r = lane & 31, h = lane >> 5;
+  const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), nw = T >> 6;
   NFP_STAMP_INIT();  // (diagnostic build: stamps 7.. of the first two rounds)
   const int pg = (P + 7) >> 3;
   gemm_stage_x<NHWC>(g, Xt, xb, cb0, ncw, t, T, pre);
@@ -364,7 +486,7 @@ __device__ __forceinline__ void bwd_gemm_phase(const KP& g, const float* Wt, uin
         const int py = fdivi(rr, g.W), px = rr - py * g.W;
         const int dy = j / K - R, dx = j % K - R;
         if (py + dy >= 0 && py + dy < g.H && px + dx >= 0 && px + dx < g.W) {
-          const int ts = max(0, (32 * (i0 + ri) - band) & ~15);
+          const int ts = gemm_ts(i0 + ri, band);
           const int tt = rr + dy * g.W + dx - ts;   // 0 <= tt < 16 * KW
           const float w = Wt[rr * K2 + j];
           const uint32_t hi = __float_as_uint(w) & 0xFFFF0000u;
@@ -380,80 +502,119 @@ __device__ __forceinline__ void bwd_gemm_phase(const KP& g, const float* Wt, uin
     // ---- output tiles (row tile, channel tile), one wavefront each -----------------------------------------------
     for (int ot = wave; ot < nrt * nct; ot += nw) {
       const int ri = fdivi(ot, nct), ct = ot - ri * nct;
-      const int it = i0 + ri, ts = max(0, (32 * it - band) & ~15);
-      const int ks = min(KW, (P - ts + 15) >> 4);   // steps whose pixels exist
-      const uint4* Wh = Wd + (long long)(ri * 2 * 32 + r) * wq + h;
-      const uint4* Wl = Wh + 32 * wq;
-      const uint4* Xr = Xt + (long long)(32 * ct + r) * xq + (ts >> 3) + h;
-      // Orientation: the accumulator holds 4 CONSECUTIVE rows per register group, so the output index that is
-      // contiguous in memory goes on the rows and leaves as one 8-byte store per group: channels for
-      // channels-last (A = Xt), pixels for NCHW (A = Wd; needs P % 4 == 0 for the alignment, otherwise pixels
-      // stay on the lanes and leave as 2-byte stores).
-      const bool rows_are_channels = NHWC || (P & 3) != 0;
-      f32x16 acc;
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {  // element e of lane (r, h) is D[row (e & 3) + 8 (e >> 2) + 4 h][column r]
-        const int ch = 32 * ct + (rows_are_channels ? (e & 3) + 8 * (e >> 2) + 4 * h : r);
-        acc[e] = gg != nullptr ? gg[ch] : 0.f;
-      }
-      for (int s = 0; s < ks; ++s) {
-        const bf16x8 wh = __builtin_bit_cast(bf16x8, Wh[2 * s]), wl = __builtin_bit_cast(bf16x8, Wl[2 * s]);
-        const bf16x8 xv = __builtin_bit_cast(bf16x8, Xr[2 * s]);
-        if (rows_are_channels) {
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xv, wl, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xv, wh, acc, 0, 0, 0);
-        } else {
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, xv, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xv, acc, 0, 0, 0);
-        }
-      }
-      if (NHWC) {            // D[row = channel][col = pixel]: 4 consecutive channels of pixel r per register group
-        // Lane (r, h) holds channels 4h + {0-3, 8-11, 16-19, 24-27} of pixel r: four 8-byte pieces, and four store
-        // instructions of 64 scattered pieces each were the longest part of a round (the texture path takes an address
-        // per lane: 12 tiles x 4 x 64 per round).  v_permlane32_swap trades the packed groups between lanes r and
-        // r + 32, so that each holds 8 consecutive channels twice: two 16-byte stores.
-        const int pp = 32 * it + r;
-        uint32_t pk[8];
-#pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-          pk[2 * gq] = f32_to_bf16x2(acc[4 * gq], acc[4 * gq + 1]);
-          pk[2 * gq + 1] = f32_to_bf16x2(acc[4 * gq + 2], acc[4 * gq + 3]);
-        }
-#pragma unroll
-        for (int gp = 0; gp < 4; gp += 2) {   // (groups gp, gp + 1): the upper lanes' gp <-> the lower lanes' gp + 1
-#pragma unroll
-          for (int d = 0; d < 2; ++d) {
-            const auto sw = __builtin_amdgcn_permlane32_swap(pk[2 * gp + d], pk[2 * gp + 2 + d], false, false);
-            pk[2 * gp + d] = sw[0];
-            pk[2 * gp + 2 + d] = sw[1];
-          }
-        }
-        if (pp < P) {
-          uint16_t* dst = gxb + (long long)pp * C + cb0 + 32 * ct + 8 * h;
-          *(uint4*)dst = make_uint4(pk[0], pk[1], pk[2], pk[3]);          // channels 8h .. 8h + 7
-          *(uint4*)(dst + 16) = make_uint4(pk[4], pk[5], pk[6], pk[7]);   // channels 16 + 8h .. 16 + 8h + 7
-        }
-      } else if ((P & 3) == 0) {  // D[row = pixel][col = channel]: 4 consecutive pixels of channel r per group
-        uint16_t* dst = gxb + (long long)(cb0 + 32 * ct + r) * P + 32 * it + 4 * h;
-#pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-          if (32 * it + 8 * gq + 4 * h < P) {  // (P % 4 == 0: a whole group or none)
-            uint2 w;
-            w.x = f32_to_bf16x2(acc[4 * gq], acc[4 * gq + 1]);
-            w.y = f32_to_bf16x2(acc[4 * gq + 2], acc[4 * gq + 3]);
-            *(uint2*)(dst + 8 * gq) = w;
-          }
-        }
-      } else {               // D[row = channel][col = pixel], NCHW with odd rows: lanes along pixels, 2-byte stores
-        const int pp = 32 * it + r;
-        if (pp < P) {
-#pragma unroll
-          for (int e = 0; e < 16; ++e)
-            gxb[(long long)(cb0 + 32 * ct + (e & 3) + 8 * (e >> 2) + 4 * h) * P + pp] = f32_to_bf16(acc[e]);
-        }
-      }
+      gemm_out_tile<NHWC>(g, Wd + (long long)ri * 2 * 32 * wq, Xt, i0 + ri, ct, ct, band, KW, xq, wq, gxb, cb0, lane, gg);
     }
     if (i0 == 0) NFP_STAMP(11);
+  }
+  NFP_STAMP(6);
+}
+
+// Second form's staging (bwd_gemm_phase3): the image block was REQUESTED as a whole, as in the first form (a chunk's loads
+// issued one chunk ahead arrive 2-3 us later — three times the chunk's tiles), and is committed chunk by chunk as the two
+// buffers come free: chunk c lives in buffer c & 1, rows = its own cx channels.  Commits the chunks [c_lo, c_hi): this
+// thread's held share of them, and — loaded here — the pieces of them that no thread holds.
+template <bool NHWC>
+__device__ __forceinline__ void gemm_stage3(const KP& g, uint4* Xt0, const uint16_t* xb, int cb0, int ncw, int cx, int t, int T,
+                                            GemmX<NHWC>& pre, int c_lo, int c_hi) {
+  const int P = g.P, pg = (P + 7) >> 3, xq = gemm_xq(P);
+  const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), nw = T >> 6;
+  auto row_of = [&](int ch, int c) { return Xt0 + ((long long)(c & 1) * cx + (ch - c * cx)) * xq; };  // channel ch (of the block) in chunk c
+  if constexpr (NHWC) {
+    const int co4 = ncw >> 5, nblk = co4 * ((pg + 15) >> 4);
+    auto commit = [&](uint4 (&v)[8], int k, int gq, int c) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (8 * gq + u >= P) v[u] = make_uint4(0, 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {  // channel 8k + j: its 16 bits of every pixel's piece
+        uint32_t e[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const uint4 &a = v[2 * u], &b = v[2 * u + 1];
+          const uint32_t wa = (j >> 1) == 0 ? a.x : ((j >> 1) == 1 ? a.y : ((j >> 1) == 2 ? a.z : a.w));
+          const uint32_t wb = (j >> 1) == 0 ? b.x : ((j >> 1) == 1 ? b.y : ((j >> 1) == 2 ? b.z : b.w));
+          e[u] = __builtin_amdgcn_perm(wb, wa, (j & 1) ? 0x07060302u : 0x05040100u);  // {pixel 2u, pixel 2u + 1}
+        }
+        if (gq < pg) row_of(8 * k + j, c)[gq] = make_uint4(e[0], e[1], e[2], e[3]);
+      }
+    };
+    for (int blk = wave; blk < nblk; blk += nw) {
+      const int bk = blk - fdivi(blk, co4) * co4, c = fdivi(32 * bk, cx);   // (wave-uniform: a block's 32 channels lie in one chunk)
+      if (c < c_lo || c >= c_hi) continue;
+      int k, gq;
+      gemm_block_of(blk, co4, lane, k, gq);
+      gq = min(gq, pg);  // (group pg: loads clamp to the last pixel, nothing is written)
+      if (blk == wave) {
+        commit(pre.v, k, gq, c);
+      } else {
+        uint4 v[8];
+        gemm_fetch8(v, g, xb, cb0, k, gq);
+        commit(v, k, gq, c);
+      }
+    }
+  } else if ((P & 3) == 0) {
+    const int np = ncw * pg;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {  // the pieces requested during phase A
+      const int i = t + u * T, ch = fdivi(i, pg), c = fdivi(ch, cx);
+      if (i < np && c >= c_lo && c < c_hi) row_of(ch, c)[i - ch * pg] = pre.v[u];
+    }
+    for (int i = t + 4 * T; i < np; i += T) {
+      const int ch = fdivi(i, pg), c = fdivi(ch, cx);
+      if (c >= c_lo && c < c_hi) {
+        uint4 v;
+        gemm_fetch_row(v, g, xb, cb0, pg, i);
+        row_of(ch, c)[i - ch * pg] = v;
+      }
+    }
+  } else {
+    const int np = ncw * pg;
+    for (int i = t; i < np; i += T) {
+      const int ch = fdivi(i, pg), gq = i - ch * pg, c = fdivi(ch, cx);  // pixel group fastest
+      if (c < c_lo || c >= c_hi) continue;
+      uint32_t v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int pp = min(8 * gq + u, P - 1);
+        const uint16_t e = xb[(long long)(cb0 + ch) * P + pp];
+        v[u] = 8 * gq + u < P ? e : 0;
+      }
+      row_of(ch, c)[gq] = make_uint4(v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16));
+    }
+  }
+}
+
+// Round 4, second form of the matrix-core phase B (bwd_fast<…, GEMM = 2>): the densified weights of EVERY row tile are in
+// LDS when this starts — phase A wrote them there directly (no window table, no zero / scatter rounds) — and x goes
+// through in chunks of g.Tc channel tiles, two buffers: the next chunk's loads fly under the current chunk's tiles.  One
+// barrier per chunk.  A chunk has about as many output tiles as the workgroup has wavefronts (launcher).
+template <int R, bool NHWC>
+__device__ __forceinline__ void bwd_gemm_phase3(const KP& g, const uint4* Wd, uint4* Xt0, GemmX<NHWC>& pre, const uint16_t* xb,
+                                                uint16_t* gxb, int cb0, int cb1, int t, int T, const float* gg = nullptr) {
+  const int P = g.P, band = R * g.W + R, nt = (P + 31) >> 5, KW = gemm_kw(band);
+  const int xq = gemm_xq(P), wq = odd_up(2 * KW + 1), pg = (P + 7) >> 3;
+  const int ncw = cb1 - cb0, cx = 32 * g.Tc, nch = (ncw + cx - 1) / cx;
+  const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), nw = T >> 6;
+  NFP_STAMP_INIT();
+  gemm_stage3<NHWC>(g, Xt0, xb, cb0, ncw, cx, t, T, pre, 0, 1);   // the first chunk; the second goes in under its tiles
+  for (int i = t; i < (nch > 1 ? 2 : 1) * cx * (xq - pg); i += T) {  // the rest of every row (alignment + padding) reads as zero
+    const int c = fdivi(i, xq - pg), k = i - c * (xq - pg);
+    Xt0[(long long)c * xq + pg + k] = make_uint4(0, 0, 0, 0);
+  }
+  NFP_STAMP(7);
+  for (int k = 0; k < nch; ++k) {
+    const int cbk = cb0 + k * cx, nctk = min(cx, cb1 - cbk) >> 5;
+    const uint4* Xt = Xt0 + (long long)(k & 1) * cx * xq;
+    __syncthreads();  // chunk k staged (k = 0: and every Wd row complete); chunk k - 1's tiles are done: its buffer is free
+    if (k == 0) NFP_STAMP(8);
+    if (k + 1 < nch) gemm_stage3<NHWC>(g, Xt0, xb, cb0, ncw, cx, t, T, pre, k + 1, k + 2);
+    if (k == 1) NFP_STAMP(10);
+    for (int ot = wave; ot < nt * nctk; ot += nw) {
+      const int it = fdivi(ot, nctk), ctx = ot - it * nctk;
+      gemm_out_tile<NHWC>(g, Wd + (long long)it * 2 * 32 * wq, Xt, it, ctx, k * g.Tc + ctx, band, KW, xq, wq, gxb, cb0, lane, gg);
+    }
+    if (k == 0) NFP_STAMP(9);
+    if (k == 1) NFP_STAMP(11);
   }
   NFP_STAMP(6);
 }
@@ -466,7 +627,7 @@ struct L_BRQ {
 // ---- backward -------------------------------------------------------------------------------
 // POOL: grad_out is not a map but the gradients of the two pooled outputs: go[b,n,p] = gnfpm[b,n]/P
 // for every p, and every grad_x[b,c,p] also receives ggap[b,c]/P (adjoint of the two means).
-template <int R, int M, bool BF, bool NHWC, bool POOL = false, bool GEMM = false>
+template <int R, int M, bool BF, bool NHWC, bool POOL = false, int GEMM = 0>   // GEMM: 0 vector phase B, 1 / 2 matrix cores
 __global__ void __launch_bounds__(GEMM ? 1024 : kBwdThreads) bwd_fast(const KP g, const void* __restrict__ x,
                                                         const void* __restrict__ go, const void* __restrict__ out,
                                                         const float* __restrict__ saved, void* __restrict__ gx,
@@ -478,6 +639,7 @@ __global__ void __launch_bounds__(GEMM ? 1024 : kBwdThreads) bwd_fast(const KP g
   // the diagonal is folded by a phase of its own when the weights are consumed as a table (matrix cores) or the
   // window is large; for k = 3 every compute thread folds its own pixel's nine terms while it loads its weights
   constexpr bool FOLD_PHASE = GEMM || Win<R>::RAD != 1;  // (R: radius spec of nfp_tables.h::Win)
+  constexpr bool G3 = GEMM == 2;  // every row tile's densified weights written by phase A itself: bwd_gemm_phase3
   extern __shared__ __attribute__((aligned(16))) float4 lds4[];
   const int P = g.P;
   // LDS: Wt | Dt | ipn | dfn (live to the end) | pair values | x slab.  The slab lies OVER the pair values (dead
@@ -486,19 +648,27 @@ __global__ void __launch_bounds__(GEMM ? 1024 : kBwdThreads) bwd_fast(const KP g
   // the end and the GEMM's operand images are laid over it as well: Wt | ipn | dfn | Dt | pair values.  19.6 KB more for
   // Wd at config 5's shape: three row tiles per round instead of two, three rounds of zero / scatter / multiply instead
   // of four (2.2 us each: profiles/r02_j_matrix_core_backward_ab.txt).
+  // GEMM = 2: ipn | dfn | Wc (centre weights) | grad(GAP) of the block (POOL) | Wd of every row tile | pair values | Dt, the
+  // x chunks (two buffers) over the last two once the diagonal is folded.
   float* Wt = (float*)lds4;        // [P][K2] gathered weights
-  float* ipn = GEMM ? Wt + P * K2 : Wt + 2 * P * K2;   // [P] 1 / max(|x_p|, eps)
+  float* ipn = G3 ? Wt : (GEMM ? Wt + P * K2 : Wt + 2 * P * K2);   // [P] 1 / max(|x_p|, eps)
   float* dfn = ipn + P;            // [P] -1 / (|x_p| max(|x_p|, eps)), 0 where |x_p| = 0
-  float* Dt = GEMM ? (float*)(lds4 + ((P * K2 + 2 * P + 3) >> 2)) : Wt + P * K2;   // [P][K2] diagonal terms collected per slot
-  float4* pv4 = GEMM ? (float4*)Dt + ((P * K2 + 3) >> 2) : lds4 + ((2 * P * K2 + 2 * P + 3) >> 2);
+  float* Wc = dfn + P;             // (GEMM = 2) [P] centre weights before the fold
+  const int g3_band = Win<R>::RAD * g.W + Win<R>::RAD, g3_wq = odd_up(2 * gemm_kw(g3_band) + 1);
+  const int g3_fixed4 = (3 * P + (POOL ? (int)(g.Cwg) : 0) + 3) >> 2;   // float4 slots in front of Wd
+  uint4* g3_Wd = (uint4*)(lds4 + g3_fixed4);
+  float4* g3_pv4 = (float4*)(g3_Wd + (long long)((P + 31) >> 5) * 64 * g3_wq);
+  float4* pv4 = G3 ? g3_pv4 : (GEMM ? lds4 + ((P * K2 + 2 * P + 3) >> 2) + ((P * K2 + 3) >> 2) : lds4 + ((2 * P * K2 + 2 * P + 3) >> 2));
+  float* Dt = G3 ? (float*)(g3_pv4 + (((M == NFP_COSINE ? 2 : 1) * N * P + 3) >> 2))
+                 : (GEMM ? (float*)(lds4 + ((P * K2 + 2 * P + 3) >> 2)) : Wt + P * K2);   // [P][K2] diagonal terms collected per slot
   float2* AD = (float2*)pv4;       // cosine: [N*P] {sg, sg*s} of pair o = n*P + p
   float* CC = (float*)pv4;         // L2:     [N*P] c = -+g/d
   float4* slab = g.early ? pv4 + (((M == NFP_COSINE ? 2 : 1) * N * P + 3) >> 2) : pv4;  // [Cc/4][P]
   const int b = blockIdx.x, t = threadIdx.x, T = blockDim.x;
   const int cb0 = blockIdx.y * g.Cwg, cb1 = min(g.C, cb0 + g.Cwg);
   // matrix-core variant: Xt over Dt and the pair values (dead once Wt is built and folded), Wd behind it
-  uint4* gemm_Xt = (uint4*)Dt;
-  uint4* gemm_Wd = gemm_Xt + (long long)(cb1 - cb0) * gemm_xq(P);
+  uint4* gemm_Xt = G3 ? (uint4*)g3_pv4 : (uint4*)Dt;
+  uint4* gemm_Wd = G3 ? g3_Wd : gemm_Xt + (long long)(cb1 - cb0) * gemm_xq(P);
   const uint16_t* x16 = (const uint16_t*)x + (long long)b * g.sB;
   // fused pooling tail, matrix-core variant: grad(GAP(x)) / P of this workgroup's channels goes to LDS behind Wd (read
   // from global memory in the tile loop it cost 4 of 22 us at config 5).  Two values per thread are requested here.
@@ -507,8 +677,8 @@ __global__ void __launch_bounds__(GEMM ? 1024 : kBwdThreads) bwd_fast(const KP g
   float ggv0 = 0.f, ggv1 = 0.f;
   if constexpr (POOL && GEMM) {
     const int ncw = cb1 - cb0;
-    const int band = Win<R>::RAD * g.W + Win<R>::RAD, KW = (32 + 2 * band + 30) >> 4;
-    gg_s = (float*)(gemm_Wd + (long long)g.Tc * 2 * 32 * odd_up(2 * KW + 1));
+    const int band = Win<R>::RAD * g.W + Win<R>::RAD, KW = gemm_kw(band);
+    gg_s = G3 ? Wc + P : (float*)(gemm_Wd + (long long)g.Tc * 2 * 32 * odd_up(2 * KW + 1));
     if (g.pool_gap && t < ncw) ggv0 = ggap[(long long)b * g.C + cb0 + t];
     if (g.pool_gap && t + T < ncw) ggv1 = ggap[(long long)b * g.C + cb0 + t + T];
   }
@@ -626,12 +796,24 @@ __global__ void __launch_bounds__(GEMM ? 1024 : kBwdThreads) bwd_fast(const KP g
                            // rounds hide it: [64,512,7,7] k = 5 10.97 -> 10.68 us, [256,192,14,14] 42.0 -> 41.3; k = 3
                            // measures the same either way and keeps the request at entry), 0 = none, 2 = all do
 #endif
+#ifndef NFP_G3_X_ENTRY
+#define NFP_G3_X_ENTRY 0   // 1 = the second matrix-core form requests its first x chunk at kernel entry, behind the small loads (A/B:
+                           // 16.7 vs 16.2 us at config 5 — the pair values queue behind it)
+#endif
+  if constexpr (G3 && NFP_G3_X_ENTRY) gemm_x_issue3<NHWC>(gxr, g, x16, cb0, cb1 - cb0, 32 * g.Tc, t, T, 0);
   constexpr bool X_LATE = !GEMM && (NFP_VEC_X_LATE == 2 || (NFP_VEC_X_LATE == 1 && Win<R>::RAD >= 2));
   if constexpr (!GEMM && !X_LATE) x_issue(cb0, min(g.Cc, cb1 - cb0) >> 2);
   // nothing that consumes a loaded value may be scheduled above this line (hipcc otherwise hoists consumers into
   // the load sequence and stalls the remaining loads behind a vmcnt wait)
   __builtin_amdgcn_sched_barrier(0);
   NFP_STAMP(1);
+  if constexpr (G3) {   // Wd: whatever phase A does not write reads as zero; Dt: slots outside the image — under the first loads' latency
+    const int nwd = ((P + 31) >> 5) * 64 * g3_wq;
+    for (int i = t; i < nwd; i += T) g3_Wd[i] = make_uint4(0, 0, 0, 0);
+    if constexpr (Win<R>::RAD >= 2)
+      for (int i = t; i < P * K2; i += T) Dt[i] = 0.f;
+    __builtin_amdgcn_sched_barrier(0);
+  }
   // A1: per-pair values, in the memory order of grad_out / out
   // (first round outside the loop: hipcc's wait-count pass is exact in straight-line code only, and a wait that
   // also covers the x block just requested would put its whole latency in front of phase A)
@@ -678,7 +860,8 @@ __global__ void __launch_bounds__(GEMM ? 1024 : kBwdThreads) bwd_fast(const KP g
     ipn[t] = fmaf(nrm, g.gf, ip * g.ngf);                                     // (GFC: the norm itself — nfp_common.h::cross_f)
     dfn[t] = nrm > 0.f ? -fmaf(1.f, g.gf, g.nuf * ip * g.ngf) * __builtin_amdgcn_rcpf(nrm) : 0.f;
   }
-  if constexpr (SYM) {  // slots before the centre whose pixel lies outside the image keep this 0
+  if constexpr (G3) {   // (Wd and Dt were zeroed while the first loads were in flight)
+  } else if constexpr (SYM) {  // slots before the centre whose pixel lies outside the image keep this 0
     if constexpr (GEMM) {   // (Wt and Dt apart: see the layout above)
       for (int i = t; i < P * K2; i += T) {
         Wt[i] = 0.f;
@@ -702,6 +885,17 @@ __global__ void __launch_bounds__(GEMM ? 1024 : kBwdThreads) bwd_fast(const KP g
     __builtin_amdgcn_sched_barrier(0);
   }
 
+  // (GEMM = 2) weight of row pixel r for the pixel under its slot j, straight into the operand image: row r of its row
+  // tile, column = that pixel - the tile's first summed pixel; hi / lo halves as two bf16 images (bwd_gemm_phase's notes)
+  auto wd_put_at = [&](int r, int tpx, float w) {
+    const int it = r >> 5;
+    uint16_t* base = (uint16_t*)(g3_Wd + (long long)(it * 64 + (r & 31)) * g3_wq);
+    const uint32_t hi = __float_as_uint(w) & 0xFFFF0000u;
+    const uint32_t lo = __float_as_uint(w - __uint_as_float(hi)) >> 16;
+    const int tt = tpx - gemm_ts(it, g3_band);
+    base[tt] = (uint16_t)(hi >> 16);
+    base[(long long)32 * g3_wq * 8 + tt] = (uint16_t)lo;
+  };
   // A2: window entry (r, j) = the sum of the pairs that link r with the pixel under slot j, listed by the table
   auto gather = [&](int e2, const uint4& r0, const uint4& r1, uint32_t tqc) {
     int r, j;
@@ -752,7 +946,7 @@ __global__ void __launch_bounds__(GEMM ? 1024 : kBwdThreads) bwd_fast(const KP g
       wv = M == NFP_COSINE ? cross_f(g, ipn[r], ipn[tt]) * S : (g.diff ? (M == kNormP1 ? S : -S) : 0.f);
       if (SYM && tqc != 0xFFFFu) {  // the same pairs, seen from t
         const int em = tt * K2 + (K2 - 1 - j);
-        Wt[em] = wv;
+        if constexpr (G3) wd_put_at(tt, r, wv); else Wt[em] = wv;   // (t's slot K2 - 1 - j is r: inside the image)
         Dt[em] = M == NFP_COSINE ? Dj * diag_f(g, ipn[tt], ipn[r]) : Dm;
       }
       if (M == NFP_COSINE) Dj *= diag_f(g, ipn[r], ipn[tt]);
@@ -791,7 +985,12 @@ __global__ void __launch_bounds__(GEMM ? 1024 : kBwdThreads) bwd_fast(const KP g
         }
       }
     }
-    Wt[e] = wv;
+    if constexpr (G3) {   // (tq = the pixel under the slot, 0xFFFF outside the image: nothing is summed there)
+      if (j == K2 / 2) Wc[r] = wv;
+      else if (tqc != 0xFFFFu) wd_put_at(r, (int)tqc, wv);
+    } else {
+      Wt[e] = wv;
+    }
     Dt[e] = Dj;
   };
   if constexpr (GEMM) {
@@ -802,7 +1001,11 @@ __global__ void __launch_bounds__(GEMM ? 1024 : kBwdThreads) bwd_fast(const KP g
 #pragma unroll
     for (int k = 0; k < PRE; ++k) {
       if (k < 3) {
-        gemm_x_issue<NHWC>(gxr, g, x16, cb0, cb1 - cb0, t, T, k);
+        if constexpr (G3) {
+          if (k + NFP_G3_X_ENTRY < 3) gemm_x_issue3<NHWC>(gxr, g, x16, cb0, cb1 - cb0, 32 * g.Tc, t, T, k + NFP_G3_X_ENTRY);
+        } else {
+          gemm_x_issue<NHWC>(gxr, g, x16, cb0, cb1 - cb0, t, T, k);
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
       if (t + k * T < NE) gather(t + k * T, prw0[k], prw1[k], ptq[k]);
@@ -835,19 +1038,23 @@ __global__ void __launch_bounds__(GEMM ? 1024 : kBwdThreads) bwd_fast(const KP g
   if constexpr (FOLD_PHASE) {
     // A3: the diagonal — every pair that contains r pulls on x_r itself — folded in a fixed order
     for (int r = t; r < P; r += T) {
-      float s = Wt[r * K2 + K2 / 2];
+      float s = G3 ? Wc[r] : Wt[r * K2 + K2 / 2];
       const float fac = M == NFP_COSINE ? dfn[r] : 1.f;
 #pragma unroll
       for (int j = 0; j < K2; ++j) s = fmaf(fac, Dt[r * K2 + j], s);
-      Wt[r * K2 + K2 / 2] = s;
+      if constexpr (G3) wd_put_at(r, r, s); else Wt[r * K2 + K2 / 2] = s;
     }
     __syncthreads();
   }
   NFP_STAMP(4);
   if constexpr (GEMM) {
     // (the pair values behind the tables are dead: their LDS becomes the GEMM's operand images)
-    bwd_gemm_phase<R, NHWC>(g, Wt, gemm_Xt, gemm_Wd, gxr, x16, (uint16_t*)gx + (long long)b * g.gB, cb0, cb1, t, T,
-                            POOL ? gg_s : nullptr);
+    if constexpr (G3)
+      bwd_gemm_phase3<Win<R>::RAD, NHWC>(g, gemm_Wd, gemm_Xt, gxr, x16, (uint16_t*)gx + (long long)b * g.gB, cb0, cb1, t, T,
+                                         POOL ? gg_s : nullptr);
+    else
+      bwd_gemm_phase<R, NHWC>(g, Wt, gemm_Xt, gemm_Wd, gxr, x16, (uint16_t*)gx + (long long)b * g.gB, cb0, cb1, t, T,
+                              POOL ? gg_s : nullptr);
     return;
   }
   float w[K2];

@@ -51,7 +51,7 @@ __global__ void __launch_bounds__(1024) bwd_gemm2(const KP g, const void* __rest
   const uint16_t* x16 = (const uint16_t*)x + (long long)b * g.sB;
   float* gg_s = nullptr;
   if constexpr (POOL) {
-    const int band = R * W + R, KW = (32 + 2 * band + 30) >> 4;
+    const int band = R * W + R, KW = gemm_kw(band);
     gg_s = (float*)(gemm_Wd + (long long)g.Tc * 2 * 32 * odd_up(2 * KW + 1));
   }
   const Rsrc gob = make_rsrc((const char*)go + (long long)b * N * P * ES, POOL ? 0 : (long long)N * P * ES);

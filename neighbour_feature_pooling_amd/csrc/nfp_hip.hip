@@ -579,7 +579,7 @@ int launch_bwd_gemm_t(KP g, const void* x, const void* go, const void* out, cons
     if (g_sw.gemm2.load(std::memory_order_relaxed) && !g.gfc && npu2 <= 1024 && !(!NHWC && (g.P & 3) && S < 2)) {
       KP h = g;
       h.Cc = h.Cwg;
-      const int band2 = R * g.W + R, KW2 = (32 + 2 * band2 + 30) >> 4;
+      const int band2 = R * g.W + R, KW2 = nfp::gemm_kw(band2);
       const size_t xq2 = (size_t)((((g.P + 15) >> 4 << 1) + 1) | 1), wq2 = (size_t)((2 * KW2 + 1) | 1);
       const int nt2 = (g.P + 31) / 32;
       const size_t wtb = (((size_t)g.P * K2 + 3) & ~(size_t)3) * 4, planes = (size_t)nfp::gemm2_plane_floats<R>(g.H, g.W) * 4;
@@ -618,7 +618,7 @@ int launch_bwd_gemm_t(KP g, const void* x, const void* go, const void* out, cons
   if (NE > nfp::kGemmPre * T || NO > 8 * T) T = 1024;
   if (NE > nfp::kGemmPre * T || NO > 8 * T) return kNotApplicable;
   g.Cc = g.Cwg;
-  const int band = g.R * g.W + g.R, KW = (32 + 2 * band + 30) >> 4;
+  const int band = g.R * g.W + g.R, KW = nfp::gemm_kw(band);
   const size_t xq = (size_t)((((g.P + 15) >> 4 << 1) + 1) | 1), wq = (size_t)((2 * KW + 1) | 1);
   // row tiles whose densified weights sit in LDS together (fewer rounds of zero / scatter / barrier): all that fit
   const int nt = (g.P + 31) / 32;
@@ -629,6 +629,27 @@ int launch_bwd_gemm_t(KP g, const void* x, const void* go, const void* out, cons
   const size_t ggb = POOL ? (size_t)g.Cwg * 4 : 0;   // grad(GAP(x)) of the block, staged behind Wd
   int rt = fixed + xt + ggb < (size_t)kLdsMax ? (int)(((size_t)kLdsMax - fixed - xt - ggb) / wd1) : 0;
   rt = std::min(rt, nt);
+  // Second form (round 4): Wd of ALL row tiles, written by phase A itself, x in chunks of `ctr` channel tiles (about one output
+  // tile per wavefront and chunk), two buffers — where that fits
+  // (measured, profiles/r04_zb_…: 17.4 -> 16.2 us at config 5, where the first form takes two rounds; where the first form
+  // holds every row tile in ONE round — 7 x 7 maps — it stays: 10.2 vs 12.2 us at [256,512,7,7], 5.96 vs 6.5 at [64,512,7,7])
+  if (const int g3 = g_sw.gemm3.load(std::memory_order_relaxed); g3 == 2 || (g3 == 1 && rt < nt)) {
+    const int nw = T / 64, nct = g.Cwg / 32;
+    int ctr = std::max(1, std::min(nct, nw / nt));
+    const int nch = (nct + ctr - 1) / ctr;
+    ctr = (nct + nch - 1) / nch;   // even chunks
+    const size_t fixed3 = ((size_t)(3 * g.P + (POOL ? g.Cwg : 0)) * 4 + 15) & ~(size_t)15;
+    const size_t xtc = (size_t)32 * ctr * xq * 16;
+    const size_t lds3 = fixed3 + (size_t)nt * wd1 + std::max((size_t)(nch > 1 ? 2 : 1) * xtc, bwd_pair_bytes(g, M, N) + dtb);
+    if (lds3 <= (size_t)kLdsMax) {
+      g.Tc = ctr;
+      g.early = 0;
+      snprintf(g_variant, sizeof(g_variant), "bwd_fast<R%d,%s,bf16,%s,mfma2%s>", R, hot_name(g), NHWC ? "nhwc" : "nchw",
+               POOL ? ",pool" : "");
+      return launch("bwd_fast_mfma2", bwd_fast<R, M, true, NHWC, POOL, 2>, dim3(g.B, S), dim3(T), lds3, st, g, x, go, out, saved,
+                    gx, ggap, gnfpm, g.ws);
+    }
+  }
   if (rt >= 2 && rt < nt) rt = (nt + ((nt + rt - 1) / rt) - 1) / ((nt + rt - 1) / rt);  // even rounds
   if (rt < std::min(2, nt)) return kNotApplicable;
   g.Tc = rt;
@@ -638,7 +659,7 @@ int launch_bwd_gemm_t(KP g, const void* x, const void* go, const void* out, cons
   if (lds > (size_t)kLdsMax) return kNotApplicable;
   snprintf(g_variant, sizeof(g_variant), "bwd_fast<R%d,%s,bf16,%s,mfma%s>", R, hot_name(g),
            NHWC ? "nhwc" : "nchw", POOL ? ",pool" : "");
-  return launch("bwd_fast_mfma", bwd_fast<R, M, true, NHWC, POOL, true>, dim3(g.B, S), dim3(T), lds, st, g, x, go, out,
+  return launch("bwd_fast_mfma", bwd_fast<R, M, true, NHWC, POOL, 1>, dim3(g.B, S), dim3(T), lds, st, g, x, go, out,
                 saved, gx, ggap, gnfpm, g.ws);
 }
 

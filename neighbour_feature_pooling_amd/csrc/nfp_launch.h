@@ -46,6 +46,8 @@ struct Switches {
                                      // band that arrives last (nfp_common.h::pool_last_band).  Measured slower than what it
                                      // replaces (profiles/r04_e_…: 8.7 vs 6.9 us at the headline shape, 103 vs 91 us at
                                      // [256,16,112,112]): off by default
+  std::atomic<int> gemm3{1};         // the matrix-core backward's second form (nfp_fast.h::bwd_gemm_phase3: every row tile's densified
+                                     // weights written by phase A, x in double-buffered chunks) where its LDS fits; 0 = round 3's form
   std::atomic<int> gemm2{1};         // A/B: the matrix-core backward with the table-free phase A (nfp_gemm2.h; -DNFP_GEMM2_ARM builds only)
   std::atomic<int> tile_dma{-1};     // the channels-last row-band forward staged by LDS-DMA into a position-major slab
                                      // (nfp_tile.h::fwd_tile, DMA): -1 = where it measured faster — bf16 maps of 64 channels and
@@ -56,6 +58,9 @@ struct Switches {
 inline Switches g_sw;
 #ifndef NFP_MFMA_DEFAULT
 #define NFP_MFMA_DEFAULT 1
+#endif
+#ifndef NFP_GEMM3_DEFAULT
+#define NFP_GEMM3_DEFAULT 1
 #endif
 inline void read_env() {
   auto flag = [](const char* name, int dflt) {
@@ -68,6 +73,10 @@ inline void read_env() {
   g_sw.mfma = flag("NFP_MFMA", NFP_MFMA_DEFAULT);
   g_sw.pool_ticket = flag("NFP_POOL_TICKET", 0);
   g_sw.gemm2 = flag("NFP_GEMM2", 1);
+  {
+    const char* e = getenv("NFP_GEMM3");   // 0 = never, 1 = where the first form needs several rounds, 2 = wherever it fits (tests)
+    g_sw.gemm3 = e ? (e[0] == '2' ? 2 : (e[0] == '1' ? 1 : 0)) : NFP_GEMM3_DEFAULT;
+  }
   {
     const char* e = getenv("NFP_TILE_DMA");
     g_sw.tile_dma = e ? (e[0] == '1' ? 1 : 0) : -1;

@@ -57,17 +57,17 @@ def test_plan_does_not_launch_or_disturb_last_variant(lib):
     (dict(shape=(64, 512, 7, 7)), "fwd_band<R1,cos,f32,nchw>x4", "bwd_fast<R1,cos,f32,nchw>"),         # headline: 4 row bands
     (dict(shape=(256, 512, 7, 7)), "fwd_band<R1,cos,f32,nchw>x1", "bwd_fast<R1,cos,f32,nchw>"),        # config 4: whole images
     (dict(shape=(256, 192, 14, 14), R=2, measure="norm", dtype=_abi.BF16), "fwd_gram<R2,l2,bf16,nchw>",
-     "bwd_fast<R2,l2,bf16,nchw,mfma>"),                                                                 # config 5
+     "bwd_fast<R2,l2,bf16,nchw,mfma2>"),                                                                 # config 5
     (dict(shape=(256, 200, 14, 14), R=2, measure="norm", dtype=_abi.BF16), "fwd_band<R2,l2,bf16,nchw>x1",
      "bwd_fast<R2,l2,bf16,nchw>"),                                                                      # C % 16 != 0
     (dict(shape=(8, 512, 7, 7), channels_last=True), "fwd_band<R1,cos,f32,nhwc>x7", "bwd_fast<R1,cos,f32,nhwc>"),
     (dict(shape=(256, 192, 14, 14), R=2, measure="norm", dtype=_abi.BF16, channels_last=True),
-     "fwd_gram<R2,l2,bf16,nhwc>", "bwd_fast<R2,l2,bf16,nhwc,mfma>"),                                   # ViT tokens: matrix cores
+     "fwd_gram<R2,l2,bf16,nhwc>", "bwd_fast<R2,l2,bf16,nhwc,mfma2>"),                                  # ViT tokens: matrix cores, second form (all 7 row tiles' weights in LDS, x in 3 chunks)
     (dict(shape=(256, 512, 7, 7), dtype=_abi.BF16), "fwd_gram<R1,cos,bf16,nchw>", "bwd_fast<R1,cos,bf16,nchw>"),   # odd rows, no channel split
     (dict(shape=(64, 512, 7, 7), dtype=_abi.BF16), "fwd_gram<R1,cos,bf16,nchw>", "bwd_fast<R1,cos,bf16,nchw,mfma>"),
     # the matrix-core backward's loop-free phase A: at most four gather rounds of its (up to 1024) threads
     (dict(shape=(4, 64, 16, 16), R=2, measure="norm", dtype=_abi.BF16, channels_last=True),
-     "fwd_gram<R2,l2,bf16,nhwc>", "bwd_fast<R2,l2,bf16,nhwc,mfma>"),                                    # 256 x 13 = 3328 entries
+     "fwd_gram<R2,l2,bf16,nhwc>", "bwd_fast<R2,l2,bf16,nhwc,mfma>"),                                     # 256 x 13 = 3328 entries; Wd of all 8 row tiles does not fit: round 3's form
     (dict(shape=(4, 64, 18, 18), R=2, measure="norm", dtype=_abi.BF16, channels_last=True),
      "fwd_gram<R2,l2,bf16,nhwc>", "bwd_fast<R2,l2,bf16,nhwc>"),                                         # 324 x 13 = 4212: vector kernel
     (dict(shape=(64, 512, 7, 7), measure="gfc", dtype=_abi.BF16, channels_last=True),

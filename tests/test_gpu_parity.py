@@ -772,13 +772,23 @@ def test_matrix_core_forward_bf16(B, C, H, W, R, meas, mode, kind, dev, monkeypa
     gx, = torch.autograd.grad(o1, x, go, retain_graph=True)
     bv = _abi.load().nfp_last_variant().decode()
     if C % 32 == 0 and bv.startswith(("bwd_fast", "bwd_gemm2")) and not (kind == "nchw" and (H * W) % 4 and B > 128):
-        assert bv.endswith(",mfma>"), bv          # (maps whose phase-A tables exceed LDS go to the general kernels)
+        assert bv.endswith((",mfma>", ",mfma2>")), bv          # (maps whose phase-A tables exceed LDS go to the general kernels)
         gx2, = torch.autograd.grad(o1, x, go, retain_graph=True)
         assert torch.equal(gx, gx2)                                  # deterministic
         nfp_switch(monkeypatch, "NFP_MFMA", "0")
-        gv, = torch.autograd.grad(o1, x, go)
-        assert not _abi.load().nfp_last_variant().decode().endswith(",mfma>")
+        gv, = torch.autograd.grad(o1, x, go, retain_graph=True)
+        assert not _abi.load().nfp_last_variant().decode().endswith((",mfma>", ",mfma2>"))
         nfp_switch(monkeypatch, "NFP_MFMA", "1")
+        # the two forms of the matrix-core phase B (nfp_fast.h: bwd_gemm_phase, bwd_gemm_phase3) hold the same weights in the
+        # same hi / lo split: they differ by the order of the float32 sums only
+        other = "0" if bv.endswith(",mfma2>") else "2"   # (2: the second form wherever its LDS fits, not only where it is faster)
+        nfp_switch(monkeypatch, "NFP_GEMM3", other)
+        g3, = torch.autograd.grad(o1, x, go, retain_graph=True)
+        bv3 = _abi.load().nfp_last_variant().decode()
+        nfp_switch(monkeypatch, "NFP_GEMM3", None)
+        assert bv3.endswith(",mfma>" if other == "0" else ",mfma2>"), bv3
+        if kind not in ("const", "smooth"):
+            assert (gx.float() - g3.float()).abs().max().item() <= 2 ** -7 * gx.float().abs().max().item()
         if kind not in ("const", "smooth"):
             assert (gx.float() - gv.float()).abs().max().item() <= 2 ** -6 * gv.float().abs().max().item()
     x64 = x.detach().double().requires_grad_(True)
@@ -1157,7 +1167,7 @@ def test_distance_maps_match_the_reference_element_wise(name, dev):
 @pytest.mark.parametrize("shape,ctor,layout,dtype,fwd,bwd", [
     ((256, 512, 7, 7), dict(R=1, measure="cosine", padding=1), "nchw", torch.float32, "fwd_band<R1,cos,f32,nchw,pool>", "bwd_fast<R1,cos,f32,nchw,pool>"),
     ((256, 512, 7, 7), dict(R=1, measure="cosine", padding=1), "nhwc", torch.bfloat16, "fwd_gram<R1,cos,bf16,nhwc,pool>", "bwd_fast<R1,cos,bf16,nhwc,mfma,pool>"),
-    ((256, 192, 14, 14), dict(R=2, measure="norm", p=2, padding=2), "nhwc", torch.bfloat16, "fwd_gram<R2,l2,bf16,nhwc,pool>", "bwd_fast<R2,l2,bf16,nhwc,mfma,pool>"),
+    ((256, 192, 14, 14), dict(R=2, measure="norm", p=2, padding=2), "nhwc", torch.bfloat16, "fwd_gram<R2,l2,bf16,nhwc,pool>", "bwd_fast<R2,l2,bf16,nhwc,mfma2,pool>"),
 ])
 def test_fused_pooling_tail_against_the_oracle_at_config_shapes(shape, ctor, layout, dtype, fwd, bwd, dev, oracle_lib):
     """The pooled kernels the train steps of configs[3] / configs[4] actually run (fwd_band / fwd_gram <...,pool>,
