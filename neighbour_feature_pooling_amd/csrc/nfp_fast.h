@@ -796,11 +796,6 @@ __global__ void __launch_bounds__(GEMM ? 1024 : kBwdThreads) bwd_fast(const KP g
                            // rounds hide it: [64,512,7,7] k = 5 10.97 -> 10.68 us, [256,192,14,14] 42.0 -> 41.3; k = 3
                            // measures the same either way and keeps the request at entry), 0 = none, 2 = all do
 #endif
-#ifndef NFP_G3_X_ENTRY
-#define NFP_G3_X_ENTRY 0   // 1 = the second matrix-core form requests its first x chunk at kernel entry, behind the small loads (A/B:
-                           // 16.7 vs 16.2 us at config 5 — the pair values queue behind it)
-#endif
-  if constexpr (G3 && NFP_G3_X_ENTRY) gemm_x_issue3<NHWC>(gxr, g, x16, cb0, cb1 - cb0, 32 * g.Tc, t, T, 0);
   constexpr bool X_LATE = !GEMM && (NFP_VEC_X_LATE == 2 || (NFP_VEC_X_LATE == 1 && Win<R>::RAD >= 2));
   if constexpr (!GEMM && !X_LATE) x_issue(cb0, min(g.Cc, cb1 - cb0) >> 2);
   // nothing that consumes a loaded value may be scheduled above this line (hipcc otherwise hoists consumers into
@@ -1002,7 +997,9 @@ __global__ void __launch_bounds__(GEMM ? 1024 : kBwdThreads) bwd_fast(const KP g
     for (int k = 0; k < PRE; ++k) {
       if (k < 3) {
         if constexpr (G3) {
-          if (k + NFP_G3_X_ENTRY < 3) gemm_x_issue3<NHWC>(gxr, g, x16, cb0, cb1 - cb0, 32 * g.Tc, t, T, k + NFP_G3_X_ENTRY);
+          // (requested at kernel entry instead — the first chunk, or all of it through branch-free buffer loads — it delays
+          // the pair values: 16.7-17.3 vs 16.2 us at config 5, profiles/r04_zb_…)
+          gemm_x_issue3<NHWC>(gxr, g, x16, cb0, cb1 - cb0, 32 * g.Tc, t, T, k);
         } else {
           gemm_x_issue<NHWC>(gxr, g, x16, cb0, cb1 - cb0, t, T, k);
         }
