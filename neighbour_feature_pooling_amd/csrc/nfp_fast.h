@@ -659,11 +659,11 @@ __global__ void __launch_bounds__(GEMM ? 1024 : kBwdThreads) bwd_fast(const KP g
   uint4* g3_Wd = (uint4*)(lds4 + g3_fixed4);
   float4* g3_pv4 = (float4*)(g3_Wd + (long long)((P + 31) >> 5) * 64 * g3_wq);
   float4* pv4 = G3 ? g3_pv4 : (GEMM ? lds4 + ((P * K2 + 2 * P + 3) >> 2) + ((P * K2 + 3) >> 2) : lds4 + ((2 * P * K2 + 2 * P + 3) >> 2));
-  float* Dt = G3 ? (float*)(g3_pv4 + (((M == NFP_COSINE ? 2 : 1) * N * P + 3) >> 2))
+  float* Dt = G3 ? (float*)(g3_pv4 + (((M == NFP_COSINE ? 2 : 1) * (N * P + 1) + 3) >> 2))
                  : (GEMM ? (float*)(lds4 + ((P * K2 + 2 * P + 3) >> 2)) : Wt + P * K2);   // [P][K2] diagonal terms collected per slot
   float2* AD = (float2*)pv4;       // cosine: [N*P] {sg, sg*s} of pair o = n*P + p
   float* CC = (float*)pv4;         // L2:     [N*P] c = -+g/d
-  float4* slab = g.early ? pv4 + (((M == NFP_COSINE ? 2 : 1) * N * P + 3) >> 2) : pv4;  // [Cc/4][P]
+  float4* slab = g.early ? pv4 + (((M == NFP_COSINE ? 2 : 1) * (N * P + 1) + 3) >> 2) : pv4;  // [Cc/4][P]
   const int b = blockIdx.x, t = threadIdx.x, T = blockDim.x;
   const int cb0 = blockIdx.y * g.Cwg, cb1 = min(g.C, cb0 + g.Cwg);
   // matrix-core variant: Xt over Dt and the pair values (dead once Wt is built and folded), Wd behind it
@@ -850,6 +850,10 @@ __global__ void __launch_bounds__(GEMM ? 1024 : kBwdThreads) bwd_fast(const KP g
       pair_round(o, gc4, oc4);
     }
   }
+  if (t == 0) {   // the zero behind the pair values (an empty list entry reads it: gather)
+    if (M == NFP_COSINE) AD[NO] = make_float2(0.f, 0.f);
+    else CC[NO] = 0.f;
+  }
   if (M == NFP_COSINE && t < P) {
     const float ip = unit_or(g, __builtin_amdgcn_rcpf(fmaxf(nrm, g.eps)));   // (DotProduct: no norm factors, no diagonal)
     ipn[t] = fmaf(nrm, g.gf, ip * g.ngf);                                     // (GFC: the norm itself — nfp_common.h::cross_f)
@@ -897,45 +901,58 @@ __global__ void __launch_bounds__(GEMM ? 1024 : kBwdThreads) bwd_fast(const KP g
     const int e = entry_of(e2, r, j);
     float S = 0.f, Dj = 0.f, Dm = 0.f, wv;  // Dj: diagonal term for r, Dm: for the pixel t on the other end
     if (j != K2 / 2) {
-      auto take = [&](uint32_t ent) {  // one list entry, predicated (the lists are packed: live entries first)
-        const bool on = ent != 0xFFFFu;
-        const int o = on ? (int)(ent & 0x7FFFu) : 0;
-        if (M == NFP_COSINE) {
-          const float2 v = AD[o];
-          S += on ? v.x : 0.f;
-          Dj += on ? v.y : 0.f;
-        } else {
-          const float cv = CC[o];
-          S += on ? cv : 0.f;
-          // 'Norm' quirk: only the pair's NEIGHBOUR is pulled (bit 15: r is the neighbour of this pair).  p = 1 with the
-          // difference weights has no diagonal at all: the pull on x_r sits inside sign(x_r - x_t)
-          const bool dall = M == kNormP1 ? false : (bool)g.diff;
-          Dj += (on && (dall || (!g.diff && (ent & 0x8000u)))) ? cv : 0.f;
-          Dm += (on && (dall || (!g.diff && !(ent & 0x8000u)))) ? cv : 0.f;
+      // One list entry.  The lists are packed (live entries first), an empty entry is 0xFFFF: its 15 index bits, clamped to
+      // NO, read the ZERO the pair values end with — no predicate on the sums.  (Round 4: at config 5 the gathers were
+      // VALU-bound — ~230 instructions per entry, 2.5 entries per thread, four wavefronts per SIMD — not LDS- or latency-
+      // bound.)  FLAGS: the 'Norm' quirk — only the pair's NEIGHBOUR is pulled (bit 15: r is the neighbour of this pair);
+      // with the difference weights every live entry counts on both diagonals (they equal S), and p = 1 has no diagonal at
+      // all: the pull on x_r sits inside sign(x_r - x_t).
+      auto takes = [&](auto flags_c) {
+        constexpr bool FLAGS = decltype(flags_c)::value;
+        auto take = [&](uint32_t ent) {
+          const int o = min((int)(ent & 0x7FFFu), NO);
+          if (M == NFP_COSINE) {
+            const float2 v = AD[o];
+            S += v.x;
+            Dj += v.y;
+          } else {
+            const float cv = CC[o];
+            S += cv;
+            if constexpr (FLAGS) {
+              Dj += (ent & 0x8000u) ? cv : 0.f;   // (an empty entry has the bit set and adds the zero)
+              Dm += (ent & 0x8000u) ? 0.f : cv;
+            }
+          }
+        };
+        auto live = [&](uint32_t w2) { return __ballot((w2 & 0xFFFFu) != 0xFFFFu) != 0; };  // wave-uniform
+        // k = 3 (one entry per thread): the first piece in one batch of LDS reads — a branch per pair of entries
+        // costs an LDS round trip each; k = 5 (ten entries per thread, most of them two links long): skip the rest
+        take(r0.x & 0xFFFFu);
+        take(r0.x >> 16);
+        if (Win<R>::RAD == 1 || live(r0.y)) {
+          take(r0.y & 0xFFFFu);
+          take(r0.y >> 16);
+          take(r0.z & 0xFFFFu);
+          take(r0.z >> 16);
+          take(r0.w & 0xFFFFu);
+          take(r0.w >> 16);
+        }
+        if (LQ > 1 && live(r1.x)) {
+          take(r1.x & 0xFFFFu);
+          take(r1.x >> 16);
+          take(r1.y & 0xFFFFu);
+          take(r1.y >> 16);
+          take(r1.z & 0xFFFFu);
+          take(r1.z >> 16);
+          take(r1.w & 0xFFFFu);
+          take(r1.w >> 16);
         }
       };
-      auto live = [&](uint32_t w2) { return __ballot((w2 & 0xFFFFu) != 0xFFFFu) != 0; };  // wave-uniform
-      // k = 3 (one entry per thread): the first piece in one batch of LDS reads — a branch per pair of entries
-      // costs an LDS round trip each; k = 5 (ten entries per thread, most of them two links long): skip the rest
-      take(r0.x & 0xFFFFu);
-      take(r0.x >> 16);
-      if (Win<R>::RAD == 1 || live(r0.y)) {
-        take(r0.y & 0xFFFFu);
-        take(r0.y >> 16);
-        take(r0.z & 0xFFFFu);
-        take(r0.z >> 16);
-        take(r0.w & 0xFFFFu);
-        take(r0.w >> 16);
-      }
-      if (LQ > 1 && live(r1.x)) {
-        take(r1.x & 0xFFFFu);
-        take(r1.x >> 16);
-        take(r1.y & 0xFFFFu);
-        take(r1.y >> 16);
-        take(r1.z & 0xFFFFu);
-        take(r1.z >> 16);
-        take(r1.w & 0xFFFFu);
-        take(r1.w >> 16);
+      if (M == NFP_COSINE || g.diff) {   // (uniform)
+        takes(std::false_type{});
+        if (M != NFP_COSINE) Dj = Dm = (M == kNormP1 ? 0.f : S);
+      } else {
+        takes(std::true_type{});
       }
       const int tt = tqc == 0xFFFFu ? r : (int)tqc;
       wv = M == NFP_COSINE ? cross_f(g, ipn[r], ipn[tt]) * S : (g.diff ? (M == kNormP1 ? S : -S) : 0.f);
@@ -999,6 +1016,7 @@ __global__ void __launch_bounds__(GEMM ? 1024 : kBwdThreads) bwd_fast(const KP g
         if constexpr (G3) {
           // (requested at kernel entry instead — the first chunk, or all of it through branch-free buffer loads — it delays
           // the pair values: 16.7-17.3 vs 16.2 us at config 5, profiles/r04_zb_…)
+          // all of it in front of the first gather round, or behind the pair values: 15.6 / 15.8 vs 15.1 us
           gemm_x_issue3<NHWC>(gxr, g, x16, cb0, cb1 - cb0, 32 * g.Tc, t, T, k);
         } else {
           gemm_x_issue<NHWC>(gxr, g, x16, cb0, cb1 - cb0, t, T, k);

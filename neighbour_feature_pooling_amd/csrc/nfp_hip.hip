@@ -470,7 +470,7 @@ int launch_fwd_band(const KP& g, const void* x, void* out, float* saved, hipStre
 // the per-pair values, which are dead once Wt is built (nfp_fast.h::bwd_fast)
 size_t bwd_fixed_bytes(const KP& g, int K2) { return ((size_t)(2 * g.P * K2 + 2 * g.P) * 4 + 15) & ~(size_t)15; }
 size_t bwd_pair_bytes(const KP& g, int M, int N) {
-  return ((size_t)((M == NFP_COSINE ? 2 : 1) * N * g.P) * 4 + 15) & ~(size_t)15;
+  return ((size_t)((M == NFP_COSINE ? 2 : 1) * (N * g.P + 1)) * 4 + 15) & ~(size_t)15;   // (+ the zero an empty list entry reads)
 }
 constexpr size_t kEarlyBudget = 96 * 1024;  // slab beside the pair values (committed during phase A) up to this much LDS
 
