@@ -25,6 +25,9 @@ def one_case(rnd, dev):
     meas = rnd.choice(["cosine", "cosine", "norm", "norm1", "dot", "gfc", "rmse"])
     mode = rnd.choice(["reflect", "zeros", "replicate"])
     cl, bf = rnd.random() < 0.5, rnd.random() < 0.25
+    if os.environ.get("STRESS_C32") == "1":   # the matrix-core kernels: bf16, whole 32-channel tiles (NFP_GEMM3=2 / 0 pick the backward's form)
+        C, bf = 32 * rnd.randint(1, 8), True
+        meas = rnd.choice(["cosine", "norm", "dot", "gfc", "rmse"])
     ctor = dict(R=R, measure="norm" if meas.startswith("norm") else meas, padding=R, padding_mode=mode)
     if meas == "norm":
         ctor["p"] = 2
@@ -74,7 +77,8 @@ if __name__ == "__main__":
     seen = {}
     for i in range(n):
         ok, desc, errs, vs = one_case(rnd, dev)
-        seen[vs[0].split("<")[0] + "/" + vs[1].split("<")[0]] = seen.get(vs[0].split("<")[0] + "/" + vs[1].split("<")[0], 0) + 1
+        key = vs[0].split("<")[0] + "/" + vs[1].split("<")[0] + (",mfma2" if "mfma2" in vs[1] else (",mfma" if "mfma" in vs[1] else ""))
+        seen[key] = seen.get(key, 0) + 1
         if not ok:
             bad += 1
             print("FAIL", desc, ["%.2e" % e for e in errs], vs, flush=True)

@@ -1424,6 +1424,29 @@ def test_random_stress_of_the_table_kernels_at_large_batches(dev):
         torch.cuda.empty_cache()
 
 
+@pytest.mark.parametrize("form", ["2", "0"])
+def test_random_stress_of_the_matrix_core_kernels(form, dev, monkeypatch):
+    """bf16 maps of whole 32-channel tiles (fwd_gram, bwd_fast<...,mfma / mfma2>): random geometries up to 20 x 20, both
+    radii, padding modes, layouts, batches up to 300, plain and pooled, against the float64 formulation — with the backward's
+    second form (nfp_fast.h::bwd_gemm_phase3) wherever its LDS fits (NFP_GEMM3=2) and with the first form only (0).
+    Long form: STRESS_C32=1 scripts/stress_big_batch.py (80 + 80 cases passed, profiles/r04_zc_…)."""
+    import random
+    sb = _load_script("stress_big_batch")
+    for k, v in (("STRESS_C32", "1"), ("STRESS_B", "1,300"), ("STRESS_HW", "20")):
+        monkeypatch.setenv(k, v)
+    nfp_switch(monkeypatch, "NFP_GEMM3", form)
+    rnd = random.Random(77 + int(form))
+    seen = set()
+    for _ in range(16):
+        ok, desc, errs, vs = sb.one_case(rnd, dev)
+        assert ok, (desc, errs, vs)
+        seen.add("mfma2" if "mfma2" in vs[1] else ("mfma" if "mfma" in vs[1] else "other"))
+        torch.cuda.empty_cache()
+    nfp_switch(monkeypatch, "NFP_GEMM3", None)
+    assert ("mfma2" if form == "2" else "mfma") in seen, seen
+    assert form == "2" or "mfma2" not in seen, seen
+
+
 def test_dot_product_backward_in_bf16_storage_has_no_nan(dev):
     """Round 3 found it with the stress above: DotProduct keeps no saved norms, so the table backward reads the OUTPUT MAP
     in their place; read as floats, a bf16 map holds NaN / Inf bit patterns, and `NaN * 0` reached the window weights.
