@@ -353,7 +353,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 // (cosine: one instruction per channel pair and direction), half the LDS bytes of the float4 slab.  With several channel
 // chunks the NEXT chunk's DMA runs under the current chunk's sums (two slabs).  See the block in the kernel.
 template <int R, int M, bool BF, bool NHWC, bool POOL = false, bool GFC = false, bool DMA = false>
-__global__ void __launch_bounds__(1024, (R == 1 ? 8 : 4)) fwd_tile(const KP g, const TileGeo tg, const void* __restrict__ x,
+__global__ void __launch_bounds__(1024, (R == 1 && M != kSymTerm ? 8 : 4)) fwd_tile(const KP g, const TileGeo tg, const void* __restrict__ x,
                                                  void* __restrict__ out, float* __restrict__ saved,
                                                  float* __restrict__ part, float* __restrict__ gap, float* __restrict__ nfpm) {
   constexpr int N = Win<R>::N, NF = Win<R>::NF;
@@ -589,6 +589,19 @@ __global__ void __launch_bounds__(1024, (R == 1 ? 8 : 4)) fwd_tile(const KP g, c
           continue;
         }
         const float4 a = Quad<BF>::get(araw);
+        if constexpr (M == kSymTerm) {   // sums of the measure's per-channel term: one wave-uniform switch per channel quad
+          sym_switch(g.measure, [&](auto mm) {
+            using MM = decltype(mm);
+#pragma unroll
+            for (int d = 0; d < NF; ++d) {
+              int dy, dx;
+              fdir<R>(d, dy, dx);
+              const float4 q = Quad<BF>::get(dy == 0 ? r0[dx] : (r0 + dy * Wu - R)[dx + R]);
+              acc[d] += (MM::term(a.x, q.x, g) + MM::term(a.y, q.y, g)) + (MM::term(a.z, q.z, g) + MM::term(a.w, q.w, g));
+            }
+          });
+          continue;
+        }
         if (M == kNormP1)   // (Norm p = 1 — the class default, nfp.py:16,141-148 — and EMD, nfp.py:207-216: sums of |.|)
           nrm += (fabsf(a.x) + fabsf(a.y)) + (fabsf(a.z) + fabsf(a.w));
         else
@@ -659,6 +672,8 @@ __global__ void __launch_bounds__(1024, (R == 1 ? 8 : 4)) fwd_tile(const KP g, c
         val = fin_prod(g, s);
       } else if (M == kNormP1) {
         val = g.osa * (g.diff ? pairv : fq);     // (no root: the sum of |.| is the norm)
+      } else if (M == kSymTerm) {
+        sym_switch(g.measure, [&](auto mm) { val = decltype(mm)::fin(pairv, 0.f, 0.f, 0.f, 0.f, g); });
       } else {
         val = fin_dist(g, g.diff ? pairv : fq);  // 'Norm' quirk (nfp.py:74 vs 85): |neighbour|
       }
@@ -752,7 +767,7 @@ __global__ void __launch_bounds__(256) pool_fold(const float* __restrict__ part,
 // out[opp n][r + d], equal up to the forward's rounding; the pull of both on |x_r| uses r's own copy, so that only the
 // gradients travel through LDS.)
 template <int R, int M, bool BF, bool NHWC, bool POOL = false, bool GFC = false, bool CST = false>
-__global__ void __launch_bounds__(1024, (R == 1 ? (CST ? 5 : 8) : 4)) bwd_tile(const KP g, const TileGeo tg, const void* __restrict__ x,
+__global__ void __launch_bounds__(1024, (R == 1 && M != kSymTerm ? (CST ? 5 : 8) : 4)) bwd_tile(const KP g, const TileGeo tg, const void* __restrict__ x,
                                                 const void* __restrict__ go, const void* __restrict__ out,
                                                 const float* __restrict__ saved, void* __restrict__ gx,
                                                 const float* __restrict__ ggap, const float* __restrict__ gnfpm) {
@@ -838,6 +853,10 @@ __global__ void __launch_bounds__(1024, (R == 1 ? (CST ? 5 : 8) : 4)) bwd_tile(c
         w[j] = sa * gc;
       } else if (M == kNormP1) {
         w[j] = ps.real ? g.osa * gc : 0.f;   // (p = 1: d out / d (a - b)[c] = +-g sign(a - b)[c]; the map itself is not needed)
+      } else if (M == kSymTerm) {
+        float c = 0.f;
+        sym_switch(g.measure, [&](auto mm) { c = decltype(mm)::coef(gc, sv[n], 0.f, 0.f, 0.f, 0.f, g).k0; });
+        w[j] = ps.real ? c : 0.f;
       } else {
         w[j] = ps.real ? dist_coef(g, gc, sv[n]) : 0.f;
       }
@@ -889,6 +908,9 @@ __global__ void __launch_bounds__(1024, (R == 1 ? (CST ? 5 : 8) : 4)) bwd_tile(c
       const float c1 = w[j];
       D += (1.f + dneg) * c2;
       w[j] = -dneg * (c1 + c2);
+    } else if (M == kSymTerm) {
+      // symmetric terms: the pair (r centre, t) and the pair (t centre, r) pull on x_r through the same d term / d a (x_r, x_t)
+      w[j] += c2;
     } else {
       const float c1 = w[j];
       D += fmaf(-dneg, c1, c2);  // 'Norm' quirk (nfp.py:74 vs 85): only the pair's NEIGHBOUR is pulled
@@ -946,7 +968,7 @@ __global__ void __launch_bounds__(1024, (R == 1 ? (CST ? 5 : 8) : 4)) bwd_tile(c
         // (Norm p = 1 on the difference weights: u's slot that points at r ITSELF — a pixel and its own padded copy,
         // replicate padding; reflect with R = 2 — lands on r's centre slot, which multiplies sign(x_r) here, not x_r: the
         // pair's gradient is sign(x_u - x_r) = sign(0) = 0, so it is dropped.  The linear measures add it: it multiplies x_r.)
-        const bool ok = oky[j / K] && okx[j % K] && !(j / K + sy == R && j % K + sx == R) && !(M == kNormP1 && j == K2 / 2);
+        const bool ok = oky[j / K] && okx[j % K] && !(j / K + sy == R && j % K + sx == R) && !((M == kNormP1 || M == kSymTerm) && j == K2 / 2);   // (kSymTerm: d term / d a (a, a) = 0 as well)
         const float val = wu[j];
         w[j] += ok ? val : 0.f;
       }
@@ -977,6 +999,28 @@ __global__ void __launch_bounds__(1024, (R == 1 ? (CST ? 5 : 8) : 4)) bwd_tile(c
       if (POOL && g.pool_gap) {
         const float4 gg = *(const float4*)(ggap + (long long)b * g.C + c0 + 4 * cq);
         r4 = make_float4(gg.x * g.invP, gg.y * g.invP, gg.z * g.invP, gg.w * g.invP);
+      }
+      if constexpr (M == kSymTerm) {
+        const float4 a = Quad<BF>::get((rc + 0 * Wu)[R]);
+        sym_switch(g.measure, [&](auto mm) {
+          using MM = decltype(mm);
+          const Coef one = {1.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int j = 0; j < K2; ++j) {
+            if (j == K2 / 2) continue;   // (no term of the pixel with itself; a zero-padded tap is a zero vector in the slab)
+            const float4 q = Quad<BF>::get((rc + (j / K - R) * Wu)[j % K]);
+            float da, db;
+            MM::grad(a.x, q.x, one, g, da, db);
+            r4.x = fmaf(w[j], da, r4.x);
+            MM::grad(a.y, q.y, one, g, da, db);
+            r4.y = fmaf(w[j], da, r4.y);
+            MM::grad(a.z, q.z, one, g, da, db);
+            r4.z = fmaf(w[j], da, r4.z);
+            MM::grad(a.w, q.w, one, g, da, db);
+            r4.w = fmaf(w[j], da, r4.w);
+          }
+        });
+        return r4;
       }
       if constexpr (M == kNormP1) {
         const float4 a = Quad<BF>::get((rc + 0 * Wu)[R]);

@@ -35,7 +35,7 @@ bool tile_geometry(const KP& g) {
 
 bool tile_ok(const KP& g, const void* x, const void* gx) {
   if (force_generic() || !tile_geometry(g) || (g.C & 3)) return false;
-  if (!hot_measure(g) && !hot_l1(g)) return false;
+  if (!hot_measure(g) && !hot_l1(g) && !hot_sym(g)) return false;
   const bool nhwc = g.sC == 1 && g.sW == g.C && g.sH == (long long)g.W * g.C;
   if (!g.contig && !nhwc) return false;
   const int es = g.dtype == NFP_F32 ? 4 : 2;
@@ -116,7 +116,7 @@ int launch_fwd_tile_t(KP g, const void* x, void* out, float* saved, hipStream_t 
       bool dma = false;
       const int dma_sw = g_sw.tile_dma.load(std::memory_order_relaxed);
       const bool dma_auto = BF && (g.C * 2) % 128 == 0;   // (8 pieces per position and chunk: where it measured faster)
-      if ((dma_sw == 1 || (dma_sw < 0 && dma_auto)) && NHWC && !POOL && G == 1 && !g.gfc && (g.C * (BF ? 2 : 4)) % 16 == 0 &&
+      if ((dma_sw == 1 || (dma_sw < 0 && dma_auto)) && M != nfp::kSymTerm && NHWC && !POOL && G == 1 && !g.gfc && (g.C * (BF ? 2 : 4)) % 16 == 0 &&
           !(((uintptr_t)x) & 15) && !((g.sB * (BF ? 2 : 4)) & 15)) {
         const int tp = g.C * (BF ? 2 : 4) / 16, npu64 = (npu + 63) & ~63;
         for (int lpc = 3; lpc >= 0; --lpc) {
@@ -290,6 +290,12 @@ int tile_forward(const KP& g, const void* x, void* out, float* saved, hipStream_
     if (pool) return kNotApplicable;
     return g.R == 1 ? fwd_rm<1, kNormP1, false>(g, x, out, saved, st, part, nb) : fwd_rm<2, kNormP1, false>(g, x, out, saved, st, part, nb);
   }
+  if (hot_sym(g)) {   // one instantiation for the four of them (nfp_measures.h::kSymTerm)
+    // (below 14 x 14 the any-geometry forward spreads the same arithmetic over more threads: [64,512,7,7] 9 vs 14 us; the
+    // backward wins at every size: 17.6-22.9 vs 20.9-28.6 us there — profiles/r04_zd_…)
+    if (pool || g.P < 196) return kNotApplicable;
+    return g.R == 1 ? fwd_rm<1, kSymTerm, false>(g, x, out, saved, st, part, nb) : fwd_rm<2, kSymTerm, false>(g, x, out, saved, st, part, nb);
+  }
   if (pool) {
     if (cosv) return g.R == 1 ? fwd_rm<1, NFP_COSINE, true>(g, x, out, saved, st, part, nb, gap, nfpm)
                               : fwd_rm<2, NFP_COSINE, true>(g, x, out, saved, st, part, nb, gap, nfpm);
@@ -308,6 +314,11 @@ int tile_backward(const KP& g, const void* x, const void* go, const void* out, c
     if (pool) return kNotApplicable;
     return g.R == 1 ? bwd_rm<1, kNormP1, false>(g, x, go, out, saved, gx, st, ggap, gnfpm)
                     : bwd_rm<2, kNormP1, false>(g, x, go, out, saved, gx, st, ggap, gnfpm);
+  }
+  if (hot_sym(g)) {
+    if (pool) return kNotApplicable;
+    return g.R == 1 ? bwd_rm<1, kSymTerm, false>(g, x, go, out, saved, gx, st, ggap, gnfpm)
+                    : bwd_rm<2, kSymTerm, false>(g, x, go, out, saved, gx, st, ggap, gnfpm);
   }
   if (pool) {
     if (cosv) return g.R == 1 ? bwd_rm<1, NFP_COSINE, true>(g, x, go, out, saved, gx, st, ggap, gnfpm) : bwd_rm<2, NFP_COSINE, true>(g, x, go, out, saved, gx, st, ggap, gnfpm);

@@ -111,6 +111,14 @@ CASES += [
     case("tile_emd_dissim_40x40x16", (2, 16, 40, 40), dict(R=1, measure="emd", padding=1, similarity=False), 82,
          full_limit=16384),
     case("tile_norm_p1_quirk_40x40x8", (1, 8, 40, 40), dict(R=1, measure="Norm", padding=1), 83, full_limit=16384),
+    # Geman-McClure / Canberra / squared chord / chi-squared 1 (nfp.py:181-193, 218-227, 310-324, 243-252): one shared
+    # instantiation of the row-band kernels (csrc/nfp_measures.h::kSymTerm)
+    case("tile_canberra_40x40x16", (2, 16, 40, 40), dict(R=1, measure="canberra", padding=1), 84, full_limit=16384),
+    case("tile_geman_k5_zeros_dissim_30x37x8", (1, 8, 30, 37),
+         dict(R=2, measure="geman", padding=2, padding_mode="zeros", similarity=False), 85),
+    case("tile_sqchord_replicate_40x40x8", (2, 8, 40, 40), dict(R=1, measure="squaredchord", padding=1, padding_mode="replicate"),
+         86, kind="relu"),
+    case("tile_chisq1_k5_56x56x24", (1, 24, 56, 56), dict(R=2, measure="chisquared1", padding=2), 87, full_limit=16384),
 ]
 
 # --- pooled NFP: adaptive_avg_pool2d(NFPPooling(feat), 1) and its input gradient, what MobileNetV3_MultiStageNFP /

@@ -116,7 +116,10 @@ ROW_BAND_GOLDENS = ["ms_cos_112x112x16", "ms_cos_56x56x24", "ms_cos_28x28x40", "
                     "tile_l2_replicate_k5_30x37x8", "tile_rmse_40x40x16", "tile_gfc_40x40x16", "tile_dot_40x40x16",
                     # the class default Norm p = 1 (nfp.py:16), its 'Norm' quirk, and EMD = the same sum (nfp.py:207-216)
                     "tile_norm_p1_40x40x16", "tile_norm_p1_k5_zeros_30x37x8", "tile_emd_dissim_40x40x16",
-                    "tile_norm_p1_quirk_40x40x8"]
+                    "tile_norm_p1_quirk_40x40x8",
+                    # Geman-McClure / Canberra / squared chord / chi-squared 1: the shared kSymTerm instantiation
+                    "tile_canberra_40x40x16", "tile_geman_k5_zeros_dissim_30x37x8", "tile_sqchord_replicate_40x40x8",
+                    "tile_chisq1_k5_56x56x24"]
 
 
 @pytest.mark.parametrize("name", ROW_BAND_GOLDENS)
@@ -143,6 +146,31 @@ def test_row_band_kernels_match_reference_golden(name, channels_last):
     bv = L.nfp_last_variant().decode()
     assert fv.startswith("fwd_tile<") and bv.startswith("bwd_tile<"), (fv, bv)
     assert_matches_golden(out.detach().cpu().numpy(), gx.cpu().numpy(), load_golden(name), TOL, 2 * TOL)
+
+
+@pytest.mark.parametrize("B,C,H,W,R,meas,mode,sim", [
+    (3, 16, 112, 112, 1, "canberra", "reflect", True), (2, 64, 56, 56, 1, "geman", "reflect", False),
+    (2, 24, 56, 56, 2, "chisquared1", "replicate", True), (9, 8, 30, 37, 1, "squaredchord", "zeros", True),
+    (2, 12, 23, 46, 2, "canberra", "zeros", False), (200, 16, 40, 40, 1, "chisquared1", "reflect", True),   # one group per position
+    (1, 260, 26, 26, 1, "geman", "replicate", True),                                                        # channel chunks
+    (64, 512, 7, 7, 1, "canberra", "reflect", True), (4, 192, 14, 14, 2, "squaredchord", "reflect", True),    # maps the table kernels serve for the hot five
+    (2, 8, 30, 37, 2, "geman", "replicate", True), (3, 12, 5, 6, 1, "chisquared1", "reflect", False)])
+@pytest.mark.parametrize("layout,dtype", [("nchw", torch.float32), ("nhwc", torch.float32), ("nhwc", torch.bfloat16)])
+def test_symmetric_term_measures_on_the_row_band_kernels(B, C, H, W, R, meas, mode, sim, layout, dtype):
+    """Geman-McClure, Canberra, squared chord and chi-squared 1 (nfp.py:181-193, 218-227, 310-324, 243-252) are sums over
+    channels of a symmetric per-channel term with no per-pixel statistic: one shared instantiation of fwd_tile / bwd_tile
+    (csrc/nfp_measures.h::kSymTerm — term / fin / coef / grad picked by the descriptor's measure) serves them at every map
+    size the row bands take.  Round 3: fwd_pairs / bwd_gather, 3.5x / 6-8x the time of the L2 kernels on large maps
+    (missing #4).  Against the oracle."""
+    dev = torch.device("cuda:0")
+    out, gx, ref, gref, fv, bv = _run(B, C, H, W, R, meas, mode, dev, dtype=dtype, channels_last=layout == "nhwc", similarity=sim)
+    short = {"canberra": "canberra", "geman": "geman", "chisquared1": "chisq1", "squaredchord": "sqchord"}[meas]
+    assert bv.startswith("bwd_tile<R%d,%s," % (R, short)), bv
+    assert fv.startswith("fwd_tile<R%d,%s," % (R, short) if H * W >= 196 else "fwd_pairs"), fv   # (small maps: the any-geometry forward)
+    to, tg = (TOL, 2 * TOL) if dtype == torch.float32 else (1e-2, 2e-2)
+    assert rel_err(out.float().cpu().numpy(), ref.numpy()) <= to, fv
+    assert rel_err(gx.float().cpu().numpy(), gref.numpy()) <= tg, bv
+    assert torch.isfinite(gx).all()
 
 
 @pytest.mark.parametrize("B,C,H,W,R,meas,mode", [
