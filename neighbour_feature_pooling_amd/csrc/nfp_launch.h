@@ -181,17 +181,17 @@ inline bool hot_measure(const KP& g) {
 // instantiations of their own of the table kernels, the radius-(1, 2) form and the row-band kernels (sums of |a - b|; a
 // gradient in sign(a - b)); plain maps only — no fused pooling tail.
 inline bool hot_l1(const KP& g) { return g.measure == NFP_NORM && g.p == 1.f; }
-// Geman-McClure, Canberra, squared chord, chi-squared 1 (nfp.py:181-193, 218-227, 310-324, 243-252): sums of a symmetric
-// per-channel term, no per-pixel statistic — one shared instantiation of the row-band kernels (nfp_measures.h::kSymTerm), any map
-// size they take; plain maps only.  (Hellinger's coefficient 1 / out is infinite on a pixel paired with its own padded copy —
-// the reference's NaN there comes from a term the row-band backward drops; chi-squared 2 and Jeffrey are not symmetric.)
+// Geman-McClure, Canberra, Hellinger, squared chord, chi-squared 1 (nfp.py:181-193, 218-227, 229-241, 310-324, 243-252): sums of
+// a symmetric per-channel term, no per-pixel statistic — one shared instantiation of the row-band kernels
+// (nfp_measures.h::kSymTerm); plain maps only.  (Chi-squared 2 and Jeffrey are not symmetric in the pair.)
 inline bool hot_sym(const KP& g) {
-  return g.measure == NFP_GEMAN || g.measure == NFP_CANBERRA || g.measure == NFP_SQUAREDCHORD || g.measure == NFP_CHISQUARED1;
+  return g.measure == NFP_GEMAN || g.measure == NFP_CANBERRA || g.measure == NFP_SQUAREDCHORD || g.measure == NFP_CHISQUARED1 ||
+         g.measure == NFP_HELLINGER;
 }
 inline const char* hot_name(const KP& g) {
   if (hot_l1(g)) return "l1";
   if (hot_sym(g))
-    return g.measure == NFP_GEMAN ? "geman" : (g.measure == NFP_CANBERRA ? "canberra" : (g.measure == NFP_SQUAREDCHORD ? "sqchord" : "chisq1"));
+    return g.measure == NFP_GEMAN ? "geman" : (g.measure == NFP_CANBERRA ? "canberra" : (g.measure == NFP_SQUAREDCHORD ? "sqchord" : (g.measure == NFP_HELLINGER ? "hellinger" : "chisq1")));
   return g.measure == NFP_COSINE ? "cos" : (g.measure == NFP_DOT ? "dot" : (g.measure == NFP_GFC ? "gfc" : (g.measure == NFP_RMSE ? "rmse" : "l2")));
 }
 inline bool force_generic() { return g_sw.force_generic.load(std::memory_order_relaxed) != 0; }

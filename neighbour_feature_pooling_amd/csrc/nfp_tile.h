@@ -884,6 +884,7 @@ __global__ void __launch_bounds__(1024, (R == 1 && M != kSymTerm ? (CST ? 5 : 8)
   NFP_STAMP(2);
 
   // ---- A2: the window weights of this thread's position, in registers (the same code for every position) -------------
+  float wself = 0.f;   // (kSymTerm) weights of pairs of a pixel with its own padded copy: see the merge below
   const float dneg = g.diff ? -1.f : 0.f;   // L2: cross weight = -c with the difference weights, 0 with the 'Norm' quirk
   float D = 0.f;
 #pragma unroll
@@ -971,6 +972,9 @@ __global__ void __launch_bounds__(1024, (R == 1 && M != kSymTerm ? (CST ? 5 : 8)
         const bool ok = oky[j / K] && okx[j % K] && !(j / K + sy == R && j % K + sx == R) && !((M == kNormP1 || M == kSymTerm) && j == K2 / 2);   // (kSymTerm: d term / d a (a, a) = 0 as well)
         const float val = wu[j];
         w[j] += ok ? val : 0.f;
+        // (... but Hellinger's coefficient on such a pair is 1 / distance = inf, and the reference's inf * 0 = NaN has to come
+        // out on that pixel: the dropped weights are kept and multiply an explicit zero in phase B)
+        if (M == kSymTerm && j == K2 / 2) wself += (oky[R] && okx[R]) ? val : 0.f;
       }
       w[K2 / 2] += wu[K2 / 2 - sy * K - sx];
     }
@@ -1020,6 +1024,10 @@ __global__ void __launch_bounds__(1024, (R == 1 && M != kSymTerm ? (CST ? 5 : 8)
             r4.w = fmaf(w[j], da, r4.w);
           }
         });
+        r4.x = fmaf(wself, 0.f, r4.x);   // (finite weights: nothing; Hellinger at distance 0: NaN, as the reference)
+        r4.y = fmaf(wself, 0.f, r4.y);
+        r4.z = fmaf(wself, 0.f, r4.z);
+        r4.w = fmaf(wself, 0.f, r4.w);
         return r4;
       }
       if constexpr (M == kNormP1) {

@@ -89,7 +89,7 @@ def test_plan_does_not_launch_or_disturb_last_variant(lib):
     (dict(shape=(2, 8, 20, 300)), "fwd_pairs", "bwd_direct"),                                          # rows too long for a band's threads
     (dict(shape=(256, 64, 56, 56), channels_last=True), "fwd_tile<R1,cos,f32,nhwc>x10", "bwd_tile<R1,cos,f32,nhwc,dense>x10"),   # 256-byte pixels
     (dict(shape=(256, 16, 112, 112), channels_last=True), "fwd_tile<R1,cos,f32,nhwc>x19", "bwd_tile<R1,cos,f32,nhwc>x19"),
-    (dict(shape=(2, 8, 100, 140), measure="hellinger"), "fwd_pairs", "bwd_gather_banded"),            # tables > LDS
+    (dict(shape=(2, 8, 100, 140), measure="chisquared2"), "fwd_pairs", "bwd_gather_banded"),          # tables > LDS
     # round 4: Geman-McClure / Canberra / squared chord / chi-squared 1 share one instantiation of the row-band kernels, any map size
     (dict(shape=(2, 8, 100, 140), measure="canberra"), "fwd_tile<R1,canberra,f32,nchw>x50", "bwd_tile<R1,canberra,f32,nchw>x50"),
     (dict(shape=(256, 64, 56, 56), measure="geman", dtype=_abi.BF16, channels_last=True), "fwd_tile<R1,geman,bf16,nhwc>x10", "bwd_tile<R1,geman,bf16,nhwc,dense>x10"),

@@ -56,7 +56,8 @@ def _run(B, C, H, W, R, meas, mode, dev, dtype=torch.float32, channels_last=Fals
     bv = L.nfp_last_variant().decode()
     gx2, = torch.autograd.grad(out, x, go)
     out2 = m(x)
-    assert torch.equal(gx, gx2) and torch.equal(out, out2), "not bitwise reproducible"
+    same = lambda a, b: torch.equal(a.isnan(), b.isnan()) and torch.equal(a.nan_to_num(), b.nan_to_num())   # (NaN where the oracle has it too)
+    assert same(gx, gx2) and same(out, out2), "not bitwise reproducible"
     orc = _oracle()
     xh = x.detach().float().contiguous().cpu().numpy()      # (bf16: what the kernel read, as float32 — exact)
     goh = go.float().cpu().numpy()
@@ -119,7 +120,7 @@ ROW_BAND_GOLDENS = ["ms_cos_112x112x16", "ms_cos_56x56x24", "ms_cos_28x28x40", "
                     "tile_norm_p1_quirk_40x40x8",
                     # Geman-McClure / Canberra / squared chord / chi-squared 1: the shared kSymTerm instantiation
                     "tile_canberra_40x40x16", "tile_geman_k5_zeros_dissim_30x37x8", "tile_sqchord_replicate_40x40x8",
-                    "tile_chisq1_k5_56x56x24"]
+                    "tile_chisq1_k5_56x56x24", "tile_hellinger_40x40x16"]
 
 
 @pytest.mark.parametrize("name", ROW_BAND_GOLDENS)
@@ -154,7 +155,12 @@ def test_row_band_kernels_match_reference_golden(name, channels_last):
     (2, 12, 23, 46, 2, "canberra", "zeros", False), (200, 16, 40, 40, 1, "chisquared1", "reflect", True),   # one group per position
     (1, 260, 26, 26, 1, "geman", "replicate", True),                                                        # channel chunks
     (64, 512, 7, 7, 1, "canberra", "reflect", True), (4, 192, 14, 14, 2, "squaredchord", "reflect", True),    # maps the table kernels serve for the hot five
-    (2, 8, 30, 37, 2, "geman", "replicate", True), (3, 12, 5, 6, 1, "chisquared1", "reflect", False)])
+    (2, 8, 30, 37, 2, "geman", "replicate", True), (3, 12, 5, 6, 1, "chisquared1", "reflect", False),
+    (2, 24, 56, 56, 1, "hellinger", "reflect", True), (3, 16, 40, 40, 2, "hellinger", "zeros", False),
+    # a pixel and its own padded copy: distance 0, coefficient 1 / distance — the gradient of both is NaN, in the oracle as in the
+    # reference (whose conv2d backward additionally turns every pixel within R of such a pair NaN, 0 * NaN under its one-hot
+    # kernels: DESIGN.md section 7; no fixture holds that case)
+    (2, 8, 33, 31, 1, "hellinger", "replicate", True)])
 @pytest.mark.parametrize("layout,dtype", [("nchw", torch.float32), ("nhwc", torch.float32), ("nhwc", torch.bfloat16)])
 def test_symmetric_term_measures_on_the_row_band_kernels(B, C, H, W, R, meas, mode, sim, layout, dtype):
     """Geman-McClure, Canberra, squared chord and chi-squared 1 (nfp.py:181-193, 218-227, 310-324, 243-252) are sums over
@@ -164,13 +170,15 @@ def test_symmetric_term_measures_on_the_row_band_kernels(B, C, H, W, R, meas, mo
     (missing #4).  Against the oracle."""
     dev = torch.device("cuda:0")
     out, gx, ref, gref, fv, bv = _run(B, C, H, W, R, meas, mode, dev, dtype=dtype, channels_last=layout == "nhwc", similarity=sim)
-    short = {"canberra": "canberra", "geman": "geman", "chisquared1": "chisq1", "squaredchord": "sqchord"}[meas]
+    short = {"canberra": "canberra", "geman": "geman", "chisquared1": "chisq1", "squaredchord": "sqchord", "hellinger": "hellinger"}[meas]
     assert bv.startswith("bwd_tile<R%d,%s," % (R, short)), bv
     assert fv.startswith("fwd_tile<R%d,%s," % (R, short) if H * W >= 196 else "fwd_pairs"), fv   # (small maps: the any-geometry forward)
     to, tg = (TOL, 2 * TOL) if dtype == torch.float32 else (1e-2, 2e-2)
     assert rel_err(out.float().cpu().numpy(), ref.numpy()) <= to, fv
-    assert rel_err(gx.float().cpu().numpy(), gref.numpy()) <= tg, bv
-    assert torch.isfinite(gx).all()
+    gh, gr = gx.float().cpu().numpy(), gref.numpy()
+    assert np.array_equal(np.isnan(gh), np.isnan(gr)), bv          # (Hellinger + replicate: NaN on the border pixels, as the reference)
+    assert np.isnan(gr).any() == (meas == "hellinger" and mode == "replicate")
+    assert rel_err(np.nan_to_num(gh), np.nan_to_num(gr)) <= tg, bv
 
 
 @pytest.mark.parametrize("B,C,H,W,R,meas,mode", [
