@@ -27,6 +27,10 @@
  *               un-gated gradient);
  *               linalg.vector_norm backward is 0 where the norm is 0;
  *               abs backward = sign (0 at 0); minimum backward splits ties 1/2.
+ *   not restated: how far a NaN travels.  Where a pair's gradient is NaN (distance 0 under Hellinger / RMSE: a border pixel and
+ *               its own replicate-padded copy) the reference's conv2d backward multiplies it by the zeros of the one-hot
+ *               kernels, so every pixel within R of the pair turns NaN; here the NaN lands on the pair's two pixels only.
+ *               No fixture holds such a case.
  */
 #include "../include/nfp.h"
 
