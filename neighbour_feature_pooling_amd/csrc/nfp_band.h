@@ -253,6 +253,18 @@ __global__ void __launch_bounds__(1024) fwd_band(const KP g, const void* __restr
       for (int cq = gl; cq < ncq; cq += G) {
         const float4* row = slab + cq * Ppb + sp;
         const float4 a = row[0];
+        if constexpr (M == kSymTerm) {   // (nfp_measures.h: a symmetric per-channel term; nrm = the sums against a zero-padded tap)
+          sym_switch(g.measure, [&](auto mm) {
+            using MM = decltype(mm);
+            nrm += (MM::term(a.x, 0.f, g) + MM::term(a.y, 0.f, g)) + (MM::term(a.z, 0.f, g) + MM::term(a.w, 0.f, g));
+#pragma unroll
+            for (int d = 0; d < NF; ++d) {
+              const float4 q = row[off[d]];
+              acc[d] += (MM::term(a.x, q.x, g) + MM::term(a.y, q.y, g)) + (MM::term(a.z, q.z, g) + MM::term(a.w, q.w, g));
+            }
+          });
+          continue;
+        }
         if (M == kNormP1)   // (Norm p = 1, nfp.py:141-148 with the class default p: sums of |.|; |x_p|_1 for the 'Norm' quirk)
           nrm += (fabsf(a.x) + fabsf(a.y)) + (fabsf(a.z) + fabsf(a.w));
         else
@@ -314,11 +326,13 @@ __global__ void __launch_bounds__(1024) fwd_band(const KP g, const void* __restr
           }
         } else {
           float d2;
-          if (g.diff)
+          if (g.diff || M == kSymTerm)   // (kSymTerm: a pixel against its own copy sums to 0 under every one of its terms)
             d2 = kind == 2 ? n2p : (kind == 1 ? 0.f : pairv);
           else
             d2 = kind == 2 ? 0.f : n2q;  // 'Norm' quirk (nfp.py:74 vs 85): |neighbour|
-          if constexpr (M == kNormP1) {
+          if constexpr (M == kSymTerm) {
+            sym_switch(g.measure, [&](auto mm) { v = decltype(mm)::fin(d2, 0.f, 0.f, 0.f, 0.f, g); });
+          } else if constexpr (M == kNormP1) {
             v = g.similarity ? -d2 : d2;   // (no root: the sum of |.| is the norm)
           } else if constexpr (VAR) {
             v = fin_dist(g, d2);

@@ -832,7 +832,13 @@ __global__ void __launch_bounds__(GEMM ? 1024 : kBwdThreads) bwd_fast(const KP g
         const float sg = g.osa * gc;
         AD[o + k] = make_float2(sg, sg * s);
       } else {
-        CC[o + k] = M == kNormP1 ? g.osa * gc : dist_coef(g, gc, oc);   // (p = 1: d out / d (a - b)[c] = +-g sign(a - b)[c])
+        if constexpr (M == kSymTerm) {   // (nfp_measures.h: the measure's own coefficient — Hellinger's needs the map value)
+          float c = 0.f;
+          sym_switch(g.measure, [&](auto mm) { c = decltype(mm)::coef(gc, oc, 0.f, 0.f, 0.f, 0.f, g).k0; });
+          CC[o + k] = c;
+        } else {
+          CC[o + k] = M == kNormP1 ? g.osa * gc : dist_coef(g, gc, oc);   // (p = 1: d out / d (a - b)[c] = +-g sign(a - b)[c])
+        }
       }
     }
   };
@@ -948,14 +954,15 @@ __global__ void __launch_bounds__(GEMM ? 1024 : kBwdThreads) bwd_fast(const KP g
           take(r1.w >> 16);
         }
       };
-      if (M == NFP_COSINE || g.diff) {   // (uniform)
+      if (M == NFP_COSINE || M == kSymTerm || g.diff) {   // (uniform)
         takes(std::false_type{});
-        if (M != NFP_COSINE) Dj = Dm = (M == kNormP1 ? 0.f : S);
+        if (M != NFP_COSINE) Dj = Dm = ((M == kNormP1 || M == kSymTerm) ? 0.f : S);
       } else {
         takes(std::true_type{});
       }
       const int tt = tqc == 0xFFFFu ? r : (int)tqc;
-      wv = M == NFP_COSINE ? cross_f(g, ipn[r], ipn[tt]) * S : (g.diff ? (M == kNormP1 ? S : -S) : 0.f);
+      // (kSymTerm: both pairs of r with t pull on x_r through the same d term / d a (x_r, x_t): their coefficients add)
+      wv = M == NFP_COSINE ? cross_f(g, ipn[r], ipn[tt]) * S : (M == kSymTerm ? S : (g.diff ? (M == kNormP1 ? S : -S) : 0.f));
       if (SYM && tqc != 0xFFFFu) {  // the same pairs, seen from t
         const int em = tt * K2 + (K2 - 1 - j);
         if constexpr (G3) wd_put_at(tt, r, wv); else Wt[em] = wv;   // (t's slot K2 - 1 - j is r: inside the image)
@@ -976,7 +983,7 @@ __global__ void __launch_bounds__(GEMM ? 1024 : kBwdThreads) bwd_fast(const KP g
         wv = cross_f(g, ipn[r], ipn[r]) * S;
         Dj *= diag_f(g, ipn[r], ipn[r]);
       } else {
-        uint32_t m = g.diff ? zm : sm;  // diff: |x_p - 0| still pulls on x_p; quirk: |x_q| with q == p
+        uint32_t m = (g.diff || M == kSymTerm) ? zm : sm;  // diff: |x_p - 0| still pulls on x_p; quirk: |x_q| with q == p
         while (m) {
           const int n = __builtin_ctz(m);
           m &= m - 1;
@@ -986,7 +993,18 @@ __global__ void __launch_bounds__(GEMM ? 1024 : kBwdThreads) bwd_fast(const KP g
         // diff, a pair whose both ends are r (replicate padding; reflect on tiny maps): distance 0.  L2's coefficient is
         // 0 there and nothing changes; RMSE's is +-inf (nfp.py:172-179 through torch's sqrt: no subgradient at 0), and
         // the reference's NaN on that pixel has to come out: +2c on the diagonal, -2c across = inf - inf
-        if (g.diff && M != kNormP1) {   // (p = 1: sign(0) = 0, nothing to add)
+        if constexpr (M == kSymTerm) {
+          // a pixel paired with its own padded copy: d term / d a (a, a) = 0 under every one of these terms, so nothing is
+          // added — but Hellinger's coefficient there is 1 / distance = inf, and the reference's inf * 0 = NaN has to come
+          // out on that pixel: the coefficients multiply an explicit zero
+          float cs = 0.f;
+          while (sm) {
+            const int n = __builtin_ctz(sm);
+            sm &= sm - 1;
+            cs += CC[n * P + r];
+          }
+          Dj = fmaf(cs, 0.f, Dj);
+        } else if (g.diff && M != kNormP1) {   // (p = 1: sign(0) = 0, nothing to add)
           while (sm) {
             const int n = __builtin_ctz(sm);
             sm &= sm - 1;
@@ -1108,7 +1126,27 @@ __global__ void __launch_bounds__(GEMM ? 1024 : kBwdThreads) bwd_fast(const KP g
           const float4 gg = *(const float4*)(ggap + (long long)b * g.C + c0 + 4 * cq);
           r4 = make_float4(gg.x * g.invP, gg.y * g.invP, gg.z * g.invP, gg.w * g.invP);
         }
-        if constexpr (M == kNormP1) {
+        if constexpr (M == kSymTerm) {
+          // grad_x[c][r] = sum_t W[r][t] d term / d a (x_r, x_t)[c]  (+ the centre weight times d term / d a (x_r, 0): zero-padded taps)
+          const float4 a = row[0];
+          sym_switch(g.measure, [&](auto mm) {
+            using MM = decltype(mm);
+            const Coef one = {1.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < K2; ++j) {
+              const float4 q = j == K2 / 2 ? make_float4(0.f, 0.f, 0.f, 0.f) : row[off[j]];
+              float da, db;
+              MM::grad(a.x, q.x, one, g, da, db);
+              r4.x = fmaf(w[j], da, r4.x);
+              MM::grad(a.y, q.y, one, g, da, db);
+              r4.y = fmaf(w[j], da, r4.y);
+              MM::grad(a.z, q.z, one, g, da, db);
+              r4.z = fmaf(w[j], da, r4.z);
+              MM::grad(a.w, q.w, one, g, da, db);
+              r4.w = fmaf(w[j], da, r4.w);
+            }
+          });
+        } else if constexpr (M == kNormP1) {
           // Norm p = 1: grad_x[c][r] = sum_t W[r][t] sign(x_r - x_t)[c]  (+ the centre weight times sign(x_r): zero-padded
           // taps with the difference weights, neighbour roles with the 'Norm' quirk)
           const float4 a = row[0];

@@ -350,10 +350,11 @@ bool fast_geometry(const KP& g) {
 }
 
 // Which calls the hot-path kernels serve; everything else runs on the generic kernels.
-bool fast_ok(const KP& g, const void* x, const void* gx) {
+// sym: also the five measures of nfp_measures.h::kSymTerm (plain single-radius maps only: their callers pass it)
+bool fast_ok(const KP& g, const void* x, const void* gx, bool sym = false) {
   if (force_generic()) return false;
   if (!fast_geometry(g) || (g.C & 3)) return false;
-  if (!hot_measure(g) && !hot_l1(g)) return false;
+  if (!hot_measure(g) && !hot_l1(g) && !(sym && hot_sym(g))) return false;
   const bool nhwc = g.sC == 1 && g.sW == g.C && g.sH == (long long)g.W * g.C;
   if (!g.contig && !nhwc) return false;
   if (!g.contig) {  // vector loads of 4 channels need natural alignment
@@ -449,6 +450,7 @@ int launch_fwd_band_t(KP g, const void* x, void* out, float* saved, hipStream_t 
            BF ? "bf16" : "f32", NHWC ? "nhwc" : "nchw", POOL ? ",pool" : "", nb);
   if (nb_out) *nb_out = nb;
   // (pooled, several bands: the bands' partial sums go to `part`; the caller folds them — pool_forward_rm)
+  if constexpr (M != kSymTerm)
   if (g.unit || g.gfc || g.d2s != 1.f)   // DotProduct / GFC / RMSE: the finalize with the run-time constants
     return launch("fwd_band", fwd_band<R, M, BF, NHWC, POOL, true>, dim3(g.B, nb), dim3(T), lds, st, g, x, out, saved, g.ws,
                   rb, gap, nfpm, part);
@@ -731,6 +733,9 @@ int64_t nfp_saved_floats(const nfp_desc* d) {
 
 }  // extern "C"
 
+#ifndef NFP_SYM_TABLE_BWD
+#define NFP_SYM_TABLE_BWD 1   // 0 = the five kSymTerm measures keep the row-band backward below 512 pixels too (A/B)
+#endif
 namespace {
 
 // What leaves the library is 0 or a negative NFP_E_* code: a launcher's internal "not applicable" can only mean
@@ -760,6 +765,9 @@ int forward_impl(const nfp_desc* d, const void* x, void* out, float* saved, void
     if (int rc = tile_forward(g, x, out, saved, st, false, nullptr, nullptr, nullptr, nullptr); rc != kNotApplicable) return rc;
   if (fast_ok(g, x, x) && hot_l1(g)) {
     const int rc = g.R == 1 ? launch_fwd_band<1, kNormP1>(g, x, out, saved, st) : launch_fwd_band<2, kNormP1>(g, x, out, saved, st);
+    if (rc != kNotApplicable) return rc;
+  } else if (hot_sym(g) && fast_ok(g, x, x, true)) {   // Geman / Canberra / Hellinger / squared chord / chi-squared 1: one instantiation
+    const int rc = g.R == 1 ? launch_fwd_band<1, kSymTerm>(g, x, out, saved, st) : launch_fwd_band<2, kSymTerm>(g, x, out, saved, st);
     if (rc != kNotApplicable) return rc;
   } else if (fast_ok(g, x, x)) {
     int rc;
@@ -847,6 +855,13 @@ int backward_impl(const nfp_desc* d, const void* x, const void* grad_out, const 
   if (g.ws != nullptr && fast_ok(g, x, grad_x) && hot_l1(g)) {
     const int rc = g.R == 1 ? launch_bwd_vec<1, kNormP1>(g, x, grad_out, out, saved, grad_x, st)
                             : launch_bwd_vec<2, kNormP1>(g, x, grad_out, out, saved, grad_x, st);
+    if (rc != kNotApplicable) return rc;
+  } else if (g.ws != nullptr && hot_sym(g) && fast_ok(g, x, grad_x, true) && NFP_SYM_TABLE_BWD && g.P < 196) {
+    // (from 14 x 14 up the row-band backward is ahead: [256,192,14,14] k = 5 97.5 vs 101.9 us, [256,64,20,20] 37.5 vs 41.4;
+    // at 7 x 7 the table kernel: [64,512,7,7] 10.1-12.3 vs 18.2-22.5 us — profiles/r04_zd_…; the forward stays on the tables
+    // up to 512 pixels: 52.7 vs 66.8 us at [256,192,14,14])
+    const int rc = g.R == 1 ? launch_bwd_vec<1, kSymTerm>(g, x, grad_out, out, saved, grad_x, st)
+                            : launch_bwd_vec<2, kSymTerm>(g, x, grad_out, out, saved, grad_x, st);
     if (rc != kNotApplicable) return rc;
   } else if (g.ws != nullptr && fast_ok(g, x, grad_x)) {
     int rc;

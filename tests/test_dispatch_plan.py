@@ -93,8 +93,8 @@ def test_plan_does_not_launch_or_disturb_last_variant(lib):
     # round 4: Geman-McClure / Canberra / squared chord / chi-squared 1 share one instantiation of the row-band kernels, any map size
     (dict(shape=(2, 8, 100, 140), measure="canberra"), "fwd_tile<R1,canberra,f32,nchw>x50", "bwd_tile<R1,canberra,f32,nchw>x50"),
     (dict(shape=(256, 64, 56, 56), measure="geman", dtype=_abi.BF16, channels_last=True), "fwd_tile<R1,geman,bf16,nhwc>x10", "bwd_tile<R1,geman,bf16,nhwc,dense>x10"),
-    (dict(shape=(64, 512, 7, 7), measure="chisquared1"), "fwd_pairs", "bwd_tile<R1,chisq1,f32,nchw>x3"),   # (forward: from 14 x 14 up)
-    (dict(shape=(256, 192, 14, 14), R=2, measure="squaredchord"), "fwd_tile<R2,sqchord,f32,nchw>x2", "bwd_tile<R2,sqchord,f32,nchw>x2"),
+    (dict(shape=(64, 512, 7, 7), measure="chisquared1"), "fwd_band<R1,chisq1,f32,nchw>x4", "bwd_fast<R1,chisq1,f32,nchw>"),   # up to 512 pixels: the table kernels
+    (dict(shape=(256, 192, 14, 14), R=2, measure="squaredchord"), "fwd_band<R2,sqchord,f32,nchw>x1", "bwd_tile<R2,sqchord,f32,nchw>x2"),   # (backward: row bands from 14 x 14 up)
     (dict(shape=(64, 512, 7, 7), measure="chisquared2"), "fwd_pairs", "bwd_gather"),                  # not symmetric: any-geometry kernels
     # round 4: the class default Norm p = 1 (nfp.py:16) and EMD = the same sum (nfp.py:207-216) on the row-band kernels
     (dict(shape=(2, 8, 100, 140), measure="emd"), "fwd_tile<R1,l1,f32,nchw>x50", "bwd_tile<R1,l1,f32,nchw>x50"),

@@ -165,14 +165,15 @@ def test_row_band_kernels_match_reference_golden(name, channels_last):
 def test_symmetric_term_measures_on_the_row_band_kernels(B, C, H, W, R, meas, mode, sim, layout, dtype):
     """Geman-McClure, Canberra, squared chord and chi-squared 1 (nfp.py:181-193, 218-227, 310-324, 243-252) are sums over
     channels of a symmetric per-channel term with no per-pixel statistic: one shared instantiation of fwd_tile / bwd_tile
-    (csrc/nfp_measures.h::kSymTerm — term / fin / coef / grad picked by the descriptor's measure) serves them at every map
-    size the row bands take.  Round 3: fwd_pairs / bwd_gather, 3.5x / 6-8x the time of the L2 kernels on large maps
+    — and of the table kernels fwd_band / bwd_fast for maps of up to 512 pixels — serves them
+    (csrc/nfp_measures.h::kSymTerm: term / fin / coef / grad picked by the descriptor's measure).  Round 3: fwd_pairs / bwd_gather, 3.5x / 6-8x the time of the L2 kernels on large maps
     (missing #4).  Against the oracle."""
     dev = torch.device("cuda:0")
     out, gx, ref, gref, fv, bv = _run(B, C, H, W, R, meas, mode, dev, dtype=dtype, channels_last=layout == "nhwc", similarity=sim)
     short = {"canberra": "canberra", "geman": "geman", "chisquared1": "chisq1", "squaredchord": "sqchord", "hellinger": "hellinger"}[meas]
-    assert bv.startswith("bwd_tile<R%d,%s," % (R, short)), bv
-    assert fv.startswith("fwd_tile<R%d,%s," % (R, short) if H * W >= 196 else "fwd_pairs"), fv   # (small maps: the any-geometry forward)
+    # (the table kernels' instantiation: the forward up to 512 pixels, the backward below 14 x 14)
+    fam = ("fwd_band" if H * W <= 512 else "fwd_tile", "bwd_fast" if H * W < 196 else "bwd_tile")
+    assert fv.startswith("%s<R%d,%s," % (fam[0], R, short)) and bv.startswith("%s<R%d,%s," % (fam[1], R, short)), (fv, bv)
     to, tg = (TOL, 2 * TOL) if dtype == torch.float32 else (1e-2, 2e-2)
     assert rel_err(out.float().cpu().numpy(), ref.numpy()) <= to, fv
     gh, gr = gx.float().cpu().numpy(), gref.numpy()
