@@ -181,17 +181,17 @@ inline bool hot_measure(const KP& g) {
 // instantiations of their own of the table kernels, the radius-(1, 2) form and the row-band kernels (sums of |a - b|; a
 // gradient in sign(a - b)); plain maps only — no fused pooling tail.
 inline bool hot_l1(const KP& g) { return g.measure == NFP_NORM && g.p == 1.f; }
-// Geman-McClure, Canberra, Hellinger, squared chord, chi-squared 1 (nfp.py:181-193, 218-227, 229-241, 310-324, 243-252): sums of
-// a symmetric per-channel term, no per-pixel statistic — one shared instantiation of the row-band kernels
-// (nfp_measures.h::kSymTerm); plain maps only.  (Chi-squared 2 and Jeffrey are not symmetric in the pair.)
+// Geman-McClure, Canberra, Hellinger, Jeffrey, squared chord, chi-squared 1 (nfp.py:181-193, 218-227, 229-241, 295-308, 310-324,
+// 243-252): sums of a symmetric per-channel term, no per-pixel statistic — one shared instantiation of the row-band and of
+// the table kernels (nfp_measures.h::kSymTerm); plain maps only.  (Chi-squared 2 is not symmetric in the pair.)
 inline bool hot_sym(const KP& g) {
   return g.measure == NFP_GEMAN || g.measure == NFP_CANBERRA || g.measure == NFP_SQUAREDCHORD || g.measure == NFP_CHISQUARED1 ||
-         g.measure == NFP_HELLINGER;
+         g.measure == NFP_HELLINGER || g.measure == NFP_JEFFREY;
 }
 inline const char* hot_name(const KP& g) {
   if (hot_l1(g)) return "l1";
   if (hot_sym(g))
-    return g.measure == NFP_GEMAN ? "geman" : (g.measure == NFP_CANBERRA ? "canberra" : (g.measure == NFP_SQUAREDCHORD ? "sqchord" : (g.measure == NFP_HELLINGER ? "hellinger" : "chisq1")));
+    return g.measure == NFP_GEMAN ? "geman" : (g.measure == NFP_CANBERRA ? "canberra" : (g.measure == NFP_SQUAREDCHORD ? "sqchord" : (g.measure == NFP_HELLINGER ? "hellinger" : (g.measure == NFP_JEFFREY ? "jeffrey" : "chisq1"))));
   return g.measure == NFP_COSINE ? "cos" : (g.measure == NFP_DOT ? "dot" : (g.measure == NFP_GFC ? "gfc" : (g.measure == NFP_RMSE ? "rmse" : "l2")));
 }
 inline bool force_generic() { return g_sw.force_generic.load(std::memory_order_relaxed) != 0; }

@@ -67,7 +67,7 @@ struct MeasNorm {
 };
 constexpr int kNormP1 = NFP_MEASURE_COUNT + 1, kNormP2 = NFP_MEASURE_COUNT + 2;  // internal dispatch ids
 // The measures that are a plain sum over channels of a SYMMETRIC per-channel term and keep no per-pixel statistic —
-// Geman-McClure, Canberra, Hellinger, squared chord, chi-squared 1 — share one instantiation of the row-band kernels (nfp_tile.h), which
+// Geman-McClure, Canberra, Hellinger, Jeffrey, squared chord, chi-squared 1 — share one instantiation of the row-band kernels (nfp_tile.h), which
 // picks term / fin / coef / grad by the descriptor's measure (a wave-uniform switch per channel quad: sym_switch, at the end
 // of this file).  Like Norm p = 1: the gradient is a per-channel function of (x_r, x_t), not linear in x.
 constexpr int kSymTerm = NFP_MEASURE_COUNT + 3;
@@ -424,6 +424,7 @@ __device__ __forceinline__ void sym_switch(int measure, F&& f) {
     case NFP_CANBERRA: f(Meas<NFP_CANBERRA>{}); break;
     case NFP_SQUAREDCHORD: f(Meas<NFP_SQUAREDCHORD>{}); break;
     case NFP_HELLINGER: f(Meas<NFP_HELLINGER>{}); break;
+    case NFP_JEFFREY: f(Meas<NFP_JEFFREY>{}); break;
     default: f(Meas<NFP_CHISQUARED1>{}); break;
   }
 }

@@ -26,7 +26,7 @@ def one_case(rnd, dev):
     mode = rnd.choice(["reflect", "zeros", "replicate"])
     cl, bf = rnd.random() < 0.5, rnd.random() < 0.25
     if os.environ.get("STRESS_SYM") == "1":   # the five measures of csrc/nfp_measures.h::kSymTerm (table kernels here)
-        meas = rnd.choice(["geman", "canberra", "hellinger", "squaredchord", "chisquared1"])
+        meas = rnd.choice(["geman", "canberra", "hellinger", "squaredchord", "chisquared1", "jeffrey"])
         if meas == "hellinger" and (mode == "replicate" or R == 2):   # (a pixel against its own copy: NaN, and how far it travels differs — DESIGN.md section 7)
             mode = "zeros"
     if os.environ.get("STRESS_C32") == "1":   # the matrix-core kernels: bf16, whole 32-channel tiles (NFP_GEMM3=2 / 0 pick the backward's form)

@@ -33,7 +33,7 @@ def one_case(rnd, dev):
     meas = rnd.choice(["cosine", "cosine", "norm", "dot", "gfc", "rmse"])
     mode = rnd.choice(["reflect", "zeros", "replicate"])
     if os.environ.get("STRESS_SYM") == "1":   # the five measures of csrc/nfp_measures.h::kSymTerm
-        meas = rnd.choice(["geman", "canberra", "hellinger", "squaredchord", "chisquared1"])
+        meas = rnd.choice(["geman", "canberra", "hellinger", "squaredchord", "chisquared1", "jeffrey"])
         if meas == "hellinger" and (mode == "replicate" or R == 2):   # (a pixel against its own copy: NaN, and how far it travels differs — DESIGN.md section 7)
             mode = "zeros"
     cl = rnd.random() < 0.5

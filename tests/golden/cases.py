@@ -120,6 +120,7 @@ CASES += [
          86, kind="relu"),
     case("tile_chisq1_k5_56x56x24", (1, 24, 56, 56), dict(R=2, measure="chisquared1", padding=2), 87, full_limit=16384),
     case("tile_hellinger_40x40x16", (2, 16, 40, 40), dict(R=1, measure="hellinger", padding=1), 89, kind="relu", full_limit=16384),
+    case("tile_jeffrey_k5_zeros_30x37x8", (1, 8, 30, 37), dict(R=2, measure="jeffrey", padding=2, padding_mode="zeros"), 90),
 ]
 
 # --- pooled NFP: adaptive_avg_pool2d(NFPPooling(feat), 1) and its input gradient, what MobileNetV3_MultiStageNFP /

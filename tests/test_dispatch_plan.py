@@ -78,7 +78,8 @@ def test_plan_does_not_launch_or_disturb_last_variant(lib):
     (dict(shape=(64, 512, 7, 7), stride=2), "fwd_pairs", "bwd_gather"),
     (dict(shape=(64, 510, 7, 7)), "fwd_pairs", "bwd_gather"),                                           # C % 4 != 0
     (dict(shape=(4, 64, 7, 7), mode="circular"), "fwd_pairs", "bwd_gather"),
-    (dict(shape=(4, 64, 7, 7), measure="jeffrey"), "fwd_pairs", "bwd_gather"),
+    (dict(shape=(4, 64, 7, 7), measure="jeffrey"), "fwd_band<R1,jeffrey,f32,nchw>x7", "bwd_fast<R1,jeffrey,f32,nchw>"),   # round 4: the shared symmetric-term instantiation
+    (dict(shape=(4, 64, 7, 7), measure="smith"), "fwd_pairs", "bwd_gather"),
     (dict(shape=(64, 512, 7, 7), measure="dot"), "fwd_band<R1,dot,f32,nchw>x4", "bwd_fast<R1,dot,f32,nchw>"),   # round 3: on the product kernels
     (dict(shape=(64, 512, 7, 7), measure="gfc"), "fwd_band<R1,gfc,f32,nchw>x4", "bwd_fast<R1,gfc,f32,nchw>"),
     (dict(shape=(64, 512, 7, 7), measure="rmse"), "fwd_band<R1,rmse,f32,nchw>x4", "bwd_fast<R1,rmse,f32,nchw>"),  # ... and the L2 kernels

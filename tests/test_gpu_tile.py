@@ -120,7 +120,7 @@ ROW_BAND_GOLDENS = ["ms_cos_112x112x16", "ms_cos_56x56x24", "ms_cos_28x28x40", "
                     "tile_norm_p1_quirk_40x40x8",
                     # Geman-McClure / Canberra / squared chord / chi-squared 1: the shared kSymTerm instantiation
                     "tile_canberra_40x40x16", "tile_geman_k5_zeros_dissim_30x37x8", "tile_sqchord_replicate_40x40x8",
-                    "tile_chisq1_k5_56x56x24", "tile_hellinger_40x40x16"]
+                    "tile_chisq1_k5_56x56x24", "tile_hellinger_40x40x16", "tile_jeffrey_k5_zeros_30x37x8"]
 
 
 @pytest.mark.parametrize("name", ROW_BAND_GOLDENS)
@@ -157,6 +157,7 @@ def test_row_band_kernels_match_reference_golden(name, channels_last):
     (64, 512, 7, 7, 1, "canberra", "reflect", True), (4, 192, 14, 14, 2, "squaredchord", "reflect", True),    # maps the table kernels serve for the hot five
     (2, 8, 30, 37, 2, "geman", "replicate", True), (3, 12, 5, 6, 1, "chisquared1", "reflect", False),
     (2, 24, 56, 56, 1, "hellinger", "reflect", True), (3, 16, 40, 40, 2, "hellinger", "zeros", False),
+    (2, 16, 56, 56, 1, "jeffrey", "replicate", True), (64, 512, 7, 7, 1, "jeffrey", "reflect", False), (2, 8, 30, 37, 2, "jeffrey", "zeros", True),
     # a pixel and its own padded copy: distance 0, coefficient 1 / distance — the gradient of both is NaN, in the oracle as in the
     # reference (whose conv2d backward additionally turns every pixel within R of such a pair NaN, 0 * NaN under its one-hot
     # kernels: DESIGN.md section 7; no fixture holds that case)
@@ -170,7 +171,7 @@ def test_symmetric_term_measures_on_the_row_band_kernels(B, C, H, W, R, meas, mo
     (missing #4).  Against the oracle."""
     dev = torch.device("cuda:0")
     out, gx, ref, gref, fv, bv = _run(B, C, H, W, R, meas, mode, dev, dtype=dtype, channels_last=layout == "nhwc", similarity=sim)
-    short = {"canberra": "canberra", "geman": "geman", "chisquared1": "chisq1", "squaredchord": "sqchord", "hellinger": "hellinger"}[meas]
+    short = {"canberra": "canberra", "geman": "geman", "chisquared1": "chisq1", "squaredchord": "sqchord", "hellinger": "hellinger", "jeffrey": "jeffrey"}[meas]
     # (the table kernels' instantiation: the forward up to 512 pixels, the backward below 14 x 14)
     fam = ("fwd_band" if H * W <= 512 else "fwd_tile", "bwd_fast" if H * W < 196 else "bwd_tile")
     assert fv.startswith("%s<R%d,%s," % (fam[0], R, short)) and bv.startswith("%s<R%d,%s," % (fam[1], R, short)), (fv, bv)
