@@ -746,21 +746,9 @@ int finish(int rc, const char* what) {
   return rc;
 }
 
-int forward_impl(const nfp_desc* d, const void* x, void* out, float* saved, void* hip_stream) {
-  KP g;
-  if (int rc = make_kp(d, &g)) return rc;
-  if (!x || !out) return fail(NFP_E_INVALID, "null tensor pointer");
-  if (g.B == 0) return NFP_OK;
-  hipStream_t st = (hipStream_t)hip_stream;
-  if (g.rs == 12) {
-    if (g.ws == nullptr || !fast_ok(g, x, x))
-      return fail(NFP_E_UNSUPPORTED, "multi-radius: cosine / dot / gfc / L2 / rmse / norm p=1 / emd on maps of at most %d pixels, "
-                  "C %% 4 == 0, dense layout, descriptor with a workspace", kBwdThreads);
-    const int rc = hot_l1(g) ? launch_fwd_band<12, kNormP1>(g, x, out, saved, st)
-                   : hot_product(g) ? launch_fwd_band<12, NFP_COSINE>(g, x, out, saved, st)
-                                    : launch_fwd_band<12, NFP_NORM>(g, x, out, saved, st);
-    return rc == kNotApplicable ? fail(NFP_E_UNSUPPORTED, "multi-radius: the map does not fit the hot-path forward") : rc;
-  }
+// The hot-path forward of a plain single-radius map, or kNotApplicable: table kernels (matrix cores first for bf16), then the
+// row-band kernels.
+int hot_forward(const KP& g, const void* x, void* out, float* saved, hipStream_t st) {
   if (g_sw.tile_first.load(std::memory_order_relaxed))
     if (int rc = tile_forward(g, x, out, saved, st, false, nullptr, nullptr, nullptr, nullptr); rc != kNotApplicable) return rc;
   if (fast_ok(g, x, x) && hot_l1(g)) {
@@ -788,6 +776,39 @@ int forward_impl(const nfp_desc* d, const void* x, void* out, float* saved, void
   }
   // maps above the table kernels' 512 pixels, or a descriptor without its tables: the row-band kernels (nfp_tile.hip)
   if (int rc = tile_forward(g, x, out, saved, st, false, nullptr, nullptr, nullptr, nullptr); rc != kNotApplicable) return rc;
+  return kNotApplicable;
+}
+
+// Attention (nfp.py:195-205) = DotProduct's sums + a softmax over the neighbours: the descriptor's parameter block as
+// DotProduct's (make_kp's run-time constants of the hot-path kernels), raw dots in float32
+KP as_dot(const KP& g) {
+  KP d = g;
+  d.measure = NFP_DOT;
+  d.similarity = 1;   // raw dots first; the sign belongs to the softmax output (nfp.py:203-204)
+  d.diff = 0;
+  d.gfc = 0; d.gf = 0.f; d.ngf = 1.f;
+  d.unit = 1; d.uf = 1.f; d.nuf = 0.f;
+  d.osa = 1.f; d.osb = 0.f; d.d2s = 1.f; d.zero0 = 1;
+  d.odtype = NFP_F32;
+  return d;
+}
+
+int forward_impl(const nfp_desc* d, const void* x, void* out, float* saved, void* hip_stream) {
+  KP g;
+  if (int rc = make_kp(d, &g)) return rc;
+  if (!x || !out) return fail(NFP_E_INVALID, "null tensor pointer");
+  if (g.B == 0) return NFP_OK;
+  hipStream_t st = (hipStream_t)hip_stream;
+  if (g.rs == 12) {
+    if (g.ws == nullptr || !fast_ok(g, x, x))
+      return fail(NFP_E_UNSUPPORTED, "multi-radius: cosine / dot / gfc / L2 / rmse / norm p=1 / emd on maps of at most %d pixels, "
+                  "C %% 4 == 0, dense layout, descriptor with a workspace", kBwdThreads);
+    const int rc = hot_l1(g) ? launch_fwd_band<12, kNormP1>(g, x, out, saved, st)
+                   : hot_product(g) ? launch_fwd_band<12, NFP_COSINE>(g, x, out, saved, st)
+                                    : launch_fwd_band<12, NFP_NORM>(g, x, out, saved, st);
+    return rc == kNotApplicable ? fail(NFP_E_UNSUPPORTED, "multi-radius: the map does not fit the hot-path forward") : rc;
+  }
+  if (int rc = hot_forward(g, x, out, saved, st); rc != kNotApplicable) return rc;
   switch (g.measure) {
     case NFP_COSINE: return launch_fwd_generic<NFP_COSINE>(g, x, out, saved, st);
     case NFP_NORM:
@@ -812,10 +833,12 @@ int forward_impl(const nfp_desc* d, const void* x, void* out, float* saved, void
       if (g.dtype != NFP_F32 && !saved)
         return fail(NFP_E_INVALID, "attention on bf16 maps needs the scratch of nfp_saved_floats (also without a backward)");
       float* dots = g.dtype == NFP_F32 ? (float*)out : saved;
-      KP gd = g;
-      gd.similarity = 1;  // raw dots first; the sign belongs to the softmax output (nfp.py:203-204)
-      gd.odtype = NFP_F32;
-      if (int rc = launch_fwd_generic<NFP_DOT>(gd, x, dots, nullptr, st)) return rc;
+      const KP gd = as_dot(g);
+      // float32 maps: DotProduct's hot-path kernels write the raw dots (round 4; bf16 maps keep float32 dots in the scratch, which
+      // only the any-geometry kernels write)
+      int rc = g.dtype == NFP_F32 ? hot_forward(gd, x, dots, nullptr, st) : kNotApplicable;
+      if (rc == kNotApplicable) rc = launch_fwd_generic<NFP_DOT>(gd, x, dots, nullptr, st);
+      if (rc) return rc;
       const long long n = (long long)g.B * g.O;
       strncat(g_variant, "+attn_softmax", sizeof(g_variant) - strlen(g_variant) - 1);
       return launch("attn_softmax_fwd", attn_softmax_fwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, g,
@@ -827,23 +850,9 @@ int forward_impl(const nfp_desc* d, const void* x, void* out, float* saved, void
   }
 }
 
-int backward_impl(const nfp_desc* d, const void* x, const void* grad_out, const void* out, const float* saved,
-                  void* grad_x, void* hip_stream) {
-  KP g;
-  if (int rc = make_kp(d, &g)) return rc;
-  if (!x || !grad_out || !out || !grad_x) return fail(NFP_E_INVALID, "null tensor pointer");
-  if ((stats_of(g.measure) > 0 || g.measure == NFP_ATTENTION) && !saved) return fail(NFP_E_INVALID, "measure %d needs the saved state of nfp_forward", g.measure);
-  if (g.B == 0) return NFP_OK;
-  hipStream_t st = (hipStream_t)hip_stream;
-  if (g.rs == 12) {
-    if (g.ws == nullptr || !fast_ok(g, x, grad_x))
-      return fail(NFP_E_UNSUPPORTED, "multi-radius: cosine / dot / gfc / L2 / rmse / norm p=1 / emd on maps of at most %d pixels, "
-                  "C %% 4 == 0, dense layout, descriptor with a workspace", kBwdThreads);
-    const int rc = hot_l1(g) ? launch_bwd_vec<12, kNormP1>(g, x, grad_out, out, saved, grad_x, st)
-                   : hot_product(g) ? launch_bwd_vec<12, NFP_COSINE>(g, x, grad_out, out, saved, grad_x, st)
-                                    : launch_bwd_vec<12, NFP_NORM>(g, x, grad_out, out, saved, grad_x, st);
-    return rc == kNotApplicable ? fail(NFP_E_UNSUPPORTED, "multi-radius: the map does not fit the hot-path backward") : rc;
-  }
+// The hot-path backward of a plain single-radius map, or kNotApplicable (as hot_forward).
+int hot_backward(const KP& g, const void* x, const void* grad_out, const void* out, const float* saved, void* grad_x,
+                 hipStream_t st) {
   if (g_sw.tile_first.load(std::memory_order_relaxed))
     if (int rc = tile_backward(g, x, grad_out, out, saved, grad_x, st, false, nullptr, nullptr); rc != kNotApplicable) return rc;
   // k = 5, float32 NCHW, maps of 14 x 14 and more: the row-band backward (window weights in registers, no 13-entry-per-pixel
@@ -874,6 +883,27 @@ int backward_impl(const nfp_desc* d, const void* x, const void* grad_out, const 
     if (rc != kNotApplicable) return rc;
   }
   if (int rc = tile_backward(g, x, grad_out, out, saved, grad_x, st, false, nullptr, nullptr); rc != kNotApplicable) return rc;
+  return kNotApplicable;
+}
+
+int backward_impl(const nfp_desc* d, const void* x, const void* grad_out, const void* out, const float* saved,
+                  void* grad_x, void* hip_stream) {
+  KP g;
+  if (int rc = make_kp(d, &g)) return rc;
+  if (!x || !grad_out || !out || !grad_x) return fail(NFP_E_INVALID, "null tensor pointer");
+  if ((stats_of(g.measure) > 0 || g.measure == NFP_ATTENTION) && !saved) return fail(NFP_E_INVALID, "measure %d needs the saved state of nfp_forward", g.measure);
+  if (g.B == 0) return NFP_OK;
+  hipStream_t st = (hipStream_t)hip_stream;
+  if (g.rs == 12) {
+    if (g.ws == nullptr || !fast_ok(g, x, grad_x))
+      return fail(NFP_E_UNSUPPORTED, "multi-radius: cosine / dot / gfc / L2 / rmse / norm p=1 / emd on maps of at most %d pixels, "
+                  "C %% 4 == 0, dense layout, descriptor with a workspace", kBwdThreads);
+    const int rc = hot_l1(g) ? launch_bwd_vec<12, kNormP1>(g, x, grad_out, out, saved, grad_x, st)
+                   : hot_product(g) ? launch_bwd_vec<12, NFP_COSINE>(g, x, grad_out, out, saved, grad_x, st)
+                                    : launch_bwd_vec<12, NFP_NORM>(g, x, grad_out, out, saved, grad_x, st);
+    return rc == kNotApplicable ? fail(NFP_E_UNSUPPORTED, "multi-radius: the map does not fit the hot-path backward") : rc;
+  }
+  if (int rc = hot_backward(g, x, grad_out, out, saved, grad_x, st); rc != kNotApplicable) return rc;
   switch (g.measure) {
     case NFP_COSINE: return launch_bwd_generic<NFP_COSINE>(g, x, grad_out, out, saved, grad_x, st);
     case NFP_NORM:
@@ -899,9 +929,14 @@ int backward_impl(const nfp_desc* d, const void* x, const void* grad_out, const 
       if (int rc = launch("attn_softmax_bwd", attn_softmax_bwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, g,
                           grad_out, out, gd))
         return rc;
-      KP gdot = g;
-      gdot.similarity = 1;
+      KP gdot = as_dot(g);
+      gdot.odtype = g.odtype;
       gdot.godtype = NFP_F32;
+      // float32 maps: DotProduct's hot-path backward on the gradient with respect to the dots (it keeps no saved state: `out` is
+      // only read in bounds)
+      if (g.dtype == NFP_F32) {
+        if (int rc = hot_backward(gdot, x, gd, out, nullptr, grad_x, st); rc != kNotApplicable) return rc;
+      }
       return launch_bwd_generic<NFP_DOT>(gdot, x, gd, out, nullptr, grad_x, st);
     }
     default:

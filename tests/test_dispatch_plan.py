@@ -83,7 +83,9 @@ def test_plan_does_not_launch_or_disturb_last_variant(lib):
     (dict(shape=(64, 512, 7, 7), measure="dot"), "fwd_band<R1,dot,f32,nchw>x4", "bwd_fast<R1,dot,f32,nchw>"),   # round 3: on the product kernels
     (dict(shape=(64, 512, 7, 7), measure="gfc"), "fwd_band<R1,gfc,f32,nchw>x4", "bwd_fast<R1,gfc,f32,nchw>"),
     (dict(shape=(64, 512, 7, 7), measure="rmse"), "fwd_band<R1,rmse,f32,nchw>x4", "bwd_fast<R1,rmse,f32,nchw>"),  # ... and the L2 kernels
-    (dict(shape=(4, 64, 7, 7), measure="attention"), "fwd_pairs+attn_softmax", "bwd_gather"),
+    (dict(shape=(4, 64, 7, 7), measure="attention"), "fwd_band<R1,dot,f32,nchw>x7+attn_softmax", "bwd_fast<R1,dot,f32,nchw>"),   # round 4: DotProduct's hot kernels under the softmax (float32 maps)
+    (dict(shape=(256, 64, 56, 56), measure="attention"), "fwd_tile<R1,dot,f32,nchw>x10+attn_softmax", "bwd_tile<R1,dot,f32,nchw>x10"),
+    (dict(shape=(4, 64, 7, 7), measure="attention", dtype=_abi.BF16), "fwd_pairs+attn_softmax", "bwd_gather"),                   # bf16 maps: float32 dots in the scratch, any-geometry kernels
     (dict(shape=(64, 64, 56, 56)), "fwd_tile<R1,cos,f32,nchw>x10", "bwd_tile<R1,cos,f32,nchw>x10"),     # > 512 px: row bands
     (dict(shape=(256, 16, 112, 112)), "fwd_tile<R1,cos,f32,nchw>x19", "bwd_tile<R1,cos,f32,nchw>x19"),
     (dict(shape=(2, 8, 100, 140)), "fwd_tile<R1,cos,f32,nchw>x50", "bwd_tile<R1,cos,f32,nchw>x50"),

@@ -183,6 +183,25 @@ def test_symmetric_term_measures_on_the_row_band_kernels(B, C, H, W, R, meas, mo
     assert rel_err(np.nan_to_num(gh), np.nan_to_num(gr)) <= tg, bv
 
 
+@pytest.mark.parametrize("B,C,H,W,R,mode,sim", [(2, 16, 40, 40, 1, "reflect", True), (3, 24, 56, 56, 2, "zeros", False),
+                                                  (64, 512, 7, 7, 1, "reflect", True), (4, 192, 14, 14, 2, "replicate", True),
+                                                  (130, 8, 30, 37, 1, "reflect", False)])
+@pytest.mark.parametrize("channels_last", [False, True])
+def test_attention_rides_on_the_dot_product_kernels(B, C, H, W, R, mode, sim, channels_last):
+    """Attention (nfp.py:195-205) = DotProduct's sums, then a softmax over the neighbours.  For float32 maps the raw dots come
+    from DotProduct's hot-path kernels (table or row-band), and the gradient with respect to the dots goes back through
+    DotProduct's hot-path backward (round 3: fwd_pairs / bwd_gather, 120 / 505 us at [256,64,56,56]).  Against the oracle."""
+    dev = torch.device("cuda:0")
+    out, gx, ref, gref, fv, bv = _run(B, C, H, W, R, "attention", mode, dev, channels_last=channels_last, similarity=sim)
+    fam = ("fwd_band", "bwd_fast") if H * W <= 512 else ("fwd_tile", "bwd_tile")
+    if R == 2 and H * W >= 196 and not channels_last:
+        fam = (fam[0], "bwd_tile")    # (k = 5 float32 NCHW from 14 x 14 up: the row-band backward, as for every hot measure)
+    assert fv.startswith("%s<R%d,dot,f32," % (fam[0], R)) and fv.endswith("+attn_softmax"), fv
+    assert bv.startswith("%s<R%d,dot,f32," % (fam[1], R)), bv
+    assert rel_err(out.cpu().numpy(), ref.numpy()) <= TOL, fv
+    assert rel_err(gx.cpu().numpy(), gref.numpy()) <= 2 * TOL, bv
+
+
 @pytest.mark.parametrize("B,C,H,W,R,meas,mode", [
     (3, 16, 112, 112, 1, "norm", "reflect"), (2, 64, 56, 56, 1, "norm", "reflect"), (2, 24, 56, 56, 2, "norm", "replicate"),
     (9, 8, 30, 37, 1, "emd", "zeros"), (2, 12, 23, 46, 2, "emd", "reflect"), (200, 16, 40, 40, 1, "norm", "reflect"),
