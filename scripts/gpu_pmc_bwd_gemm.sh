@@ -28,9 +28,9 @@ for f in glob.glob("gpurun_out/pmc_bwdg_*/**/*counter_collection.csv", recursive
     for row in csv.DictReader(open(f)):
         if "bwd_fast" in row["Kernel_Name"]:
             agg[row["Counter_Name"]].append(float(row["Counter_Value"]))
-lines = ["# bwd_fast<R2,l2,bf16,nhwc,mfma> on [256,192,14,14] bf16 channels-last, per launch (mean of 20 launches; SQ counters summed over the chip)"]
+lines = ["# bwd_fast<R2,l2,bf16,nhwc,mfma*> (whichever form the dispatcher picks) on [256,192,14,14] bf16 channels-last, per launch (mean of 20 launches; SQ counters summed over the chip)"]
 for k, v in sorted(agg.items()):
     lines.append(f"{k},{sum(v)/len(v):.0f}")
-open("gpurun_out/r02_m_config5_backward_pmc.csv", "w").write("\n".join(lines) + "\n")
+open("gpurun_out/config5_backward_pmc.csv", "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
 PY
